@@ -1,0 +1,75 @@
+"""ctypes binding of libmuzero_amd.so (the C ABI declared in include/muzero_amd.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmuzero_amd.so")
+
+
+class MuZeroAmdError(RuntimeError):
+    pass
+
+
+class TreeLayout(C.Structure):
+    _fields_ = [("B", C.c_int32), ("A", C.c_int32), ("max_nodes", C.c_int32), ("reserved", C.c_int32),
+                ("total_bytes", C.c_int64)] + [(n, C.c_int64) for n in (
+                    "child", "visit", "value_sum", "prior", "root_prior64", "reward", "num_nodes",
+                    "root_visit", "root_value_sum", "minmax", "root_is_f64", "path_node", "path_action",
+                    "path_len", "leaf_parent", "leaf_action", "status")]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "mz_version": (C.c_int, []),
+    "mz_last_error": (C.c_char_p, []),
+    "mz_tree_layout_query": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(TreeLayout)]),
+    "mz_tree_root_init": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, C.c_float, C.c_double, _P]),
+    "mz_tree_select": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, C.c_int32, _P]),
+    "mz_tree_expand_backup": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P]),
+    "mz_tree_readout": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, _P]),
+    "mz_select_action": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MuZeroAmdError(
+                f"{LIB_PATH} not found: build it with `make -C muzero_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point and turn a negative code into an exception."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        msg = lib().mz_last_error().decode(errors="replace")
+        raise MuZeroAmdError(f"{name} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, or NULL for None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

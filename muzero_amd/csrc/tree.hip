@@ -1,0 +1,454 @@
+// Device-resident search trees: one wavefront (64 lanes) per game, one lane
+// per action.  Replaces the per-node Python tree of the reference
+// (model.py:351-527).  This file must be compiled with -ffp-contract=off: the
+// selection score and the backup reproduce the reference's float32 / float64
+// arithmetic step by step, and a fused multiply-add would change the rounding.
+#pragma clang fp contract(off)
+
+#include "common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWavesPerBlock * 64;
+
+struct TreeView {
+  int B, A, N;  // N = max_nodes
+  int* child;
+  int* visit;
+  double* value_sum;
+  float* prior;
+  double* root_prior64;
+  double* reward;
+  int* num_nodes;
+  int* root_visit;
+  double* root_value_sum;
+  double* minmax;
+  int* root_is_f64;
+  int* path_node;
+  int* path_action;
+  int* path_len;
+  int* leaf_parent;
+  int* leaf_action;
+  int* status;
+};
+
+TreeView make_view(void* ws, const mz_tree_layout* L) {
+  char* p = static_cast<char*>(ws);
+  TreeView t;
+  t.B = L->B; t.A = L->A; t.N = L->max_nodes;
+  t.child = reinterpret_cast<int*>(p + L->child);
+  t.visit = reinterpret_cast<int*>(p + L->visit);
+  t.value_sum = reinterpret_cast<double*>(p + L->value_sum);
+  t.prior = reinterpret_cast<float*>(p + L->prior);
+  t.root_prior64 = reinterpret_cast<double*>(p + L->root_prior64);
+  t.reward = reinterpret_cast<double*>(p + L->reward);
+  t.num_nodes = reinterpret_cast<int*>(p + L->num_nodes);
+  t.root_visit = reinterpret_cast<int*>(p + L->root_visit);
+  t.root_value_sum = reinterpret_cast<double*>(p + L->root_value_sum);
+  t.minmax = reinterpret_cast<double*>(p + L->minmax);
+  t.root_is_f64 = reinterpret_cast<int*>(p + L->root_is_f64);
+  t.path_node = reinterpret_cast<int*>(p + L->path_node);
+  t.path_action = reinterpret_cast<int*>(p + L->path_action);
+  t.path_len = reinterpret_cast<int*>(p + L->path_len);
+  t.leaf_parent = reinterpret_cast<int*>(p + L->leaf_parent);
+  t.leaf_action = reinterpret_cast<int*>(p + L->leaf_action);
+  t.status = reinterpret_cast<int*>(p + L->status);
+  return t;
+}
+
+__device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------- root init
+__global__ __launch_bounds__(kBlock) void root_init_kernel(TreeView t, const float* __restrict__ priors,
+                                                          const double* __restrict__ noise, float keep,
+                                                          double frac) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (b >= t.B) return;
+  const size_t row = (size_t)b * t.N * t.A;  // node 0
+  if (lane < t.A) {
+    const float p = priors[(size_t)b * t.A + lane];
+    t.prior[row + lane] = p;
+    t.visit[row + lane] = 0;
+    t.value_sum[row + lane] = 0.0;
+    t.child[row + lane] = -1;
+    if (noise != nullptr) {
+      const float kept = p * keep;  // float32 product, as prior * (1 - frac) under NumPy promotion
+      t.root_prior64[(size_t)b * t.A + lane] = (double)kept + noise[(size_t)b * t.A + lane] * frac;
+    }
+  }
+  if (lane == 0) {
+    t.num_nodes[b] = 1;
+    t.root_visit[b] = 0;
+    t.root_value_sum[b] = 0.0;
+    t.minmax[2 * b] = __builtin_inf();
+    t.minmax[2 * b + 1] = -__builtin_inf();
+    t.root_is_f64[b] = noise != nullptr;
+    t.reward[(size_t)b * t.N] = 0.0;
+    t.path_len[b] = 0;
+    t.status[b] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ select
+__global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double* __restrict__ pbc,
+                                                       const double* __restrict__ sq, int table_len) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (b >= t.B) return;
+  const int A = t.A;
+  const double lo = t.minmax[2 * b], hi = t.minmax[2 * b + 1];
+  const bool root64 = t.root_is_f64[b] != 0;
+  const double ninf = -__builtin_inf();
+
+  int node = 0;
+  int parent_n = t.root_visit[b];
+  int depth = 0;
+  int bad = 0;
+  while (true) {
+    const size_t row = ((size_t)b * t.N + node) * A;
+    int n = 0, kid = -1;
+    double score = ninf;
+    if (lane < A) {
+      n = t.visit[row + lane];
+      kid = t.child[row + lane];
+      const double w = t.value_sum[row + lane];
+      const int pn = parent_n < table_len ? parent_n : table_len - 1;
+      const double c = pbc[pn] * (sq[pn] / (double)(n + 1));
+      double vs = 0.0;
+      if (n > 0) vs = hi > lo ? (w / (double)n - lo) / (hi - lo) : 0.5;
+      if (root64 && node == 0) {
+        score = c * t.root_prior64[(size_t)b * A + lane] + vs;
+      } else {
+        const float ps = (float)c * t.prior[row + lane];
+        score = (double)(ps + (float)vs);  // float32 sum, widened only to compare
+      }
+      if (!(score > ninf)) score = ninf;  // NaN and -inf never beat the initial -inf
+    }
+    // wavefront argmax, strict '>' in action order == lowest action among equals
+    double best = score;
+    int best_a = lane;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const double os = shfl_xor_f64(best, m);
+      const int oa = __shfl_xor(best_a, m);
+      if (os > best || (os == best && oa < best_a)) {
+        best = os;
+        best_a = oa;
+      }
+    }
+    best_a = wave_uniform(best_a);
+    if (!(best > ninf)) {  // the reference would return action -1 / child None here
+      bad = 1;
+      best_a = 0;
+    }
+    if (lane == 0) {
+      t.path_node[(size_t)b * t.N + depth] = node;
+      t.path_action[(size_t)b * t.N + depth] = best_a;
+    }
+    ++depth;
+    const int next = wave_uniform(__shfl(kid, best_a));
+    if (next < 0 || depth >= t.N) {
+      if (lane == 0) {
+        t.leaf_parent[b] = node;
+        t.leaf_action[b] = best_a;
+        t.path_len[b] = depth;
+        if (bad) t.status[b] = 1;
+      }
+      break;
+    }
+    parent_n = wave_uniform(__shfl(n, best_a));
+    node = next;
+  }
+}
+
+// ----------------------------------------------------------- expand + backup
+// Dynamic LDS: per wave two double arrays of max_nodes entries
+// (reward of each node on the path, value added at each node).
+__global__ __launch_bounds__(kBlock) void expand_backup_kernel(TreeView t, const float* __restrict__ priors,
+                                                              const float* __restrict__ value,
+                                                              const float* __restrict__ reward, int wave,
+                                                              double gamma) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWavesPerBlock + w;
+  if (b >= t.B) return;
+  double* rwd = reinterpret_cast<double*>(smem) + (size_t)w * 2 * t.N;
+  double* val = rwd + t.N;
+  const int A = t.A;
+  const int e = wave_uniform(t.num_nodes[b]);
+  const int len = wave_uniform(t.path_len[b]);
+  if (e >= t.N || len <= 0) {
+    if (lane == 0) t.status[b] = 2;
+    return;
+  }
+  const int parent = wave_uniform(t.leaf_parent[b]);
+  const int act = wave_uniform(t.leaf_action[b]);
+  const double leaf_reward = (double)reward[b];
+
+  // expansion: a fresh row of A edge records behind (parent, act)
+  const size_t erow = ((size_t)b * t.N + e) * A;
+  if (lane < A) {
+    t.prior[erow + lane] = priors[(size_t)b * A + lane];
+    t.visit[erow + lane] = 0;
+    t.value_sum[erow + lane] = 0.0;
+    t.child[erow + lane] = -1;
+  }
+  if (lane == 0) {
+    t.child[((size_t)b * t.N + parent) * A + act] = e;
+    t.reward[(size_t)b * t.N + e] = leaf_reward;
+    t.num_nodes[b] = e + 1;
+  }
+
+  // rewards of the nodes on the path below the root: node behind edge d is
+  // path_node[d + 1], or the new node for the last edge
+  const int* pn = t.path_node + (size_t)b * t.N;
+  const int* pa = t.path_action + (size_t)b * t.N;
+  for (int d = lane; d < len; d += 64)
+    rwd[d] = d == len - 1 ? leaf_reward : t.reward[(size_t)b * t.N + pn[d + 1]];
+  __builtin_amdgcn_wave_barrier();
+
+  // value = reward + gamma * value, leaf first (model.py:522-526); every lane
+  // runs the same recurrence on LDS broadcasts
+  double v = (double)value[b];
+  for (int d = len - 1; d >= 0; --d) {
+    if (lane == 0) val[d] = v;
+    v = rwd[d] + gamma * v;
+  }
+  const double root_add = v;
+  __builtin_amdgcn_wave_barrier();
+
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int d = lane; d < len; d += 64) {
+    const size_t idx = ((size_t)b * t.N + pn[d]) * A + pa[d];
+    double ws = t.value_sum[idx];
+    int n = t.visit[idx];
+    const double add = val[d];
+    for (int k = 0; k < wave; ++k) {
+      ws += add;
+      n += 1;
+      const double q = ws / (double)n;
+      lo = q < lo ? q : lo;
+      hi = q > hi ? q : hi;
+    }
+    t.value_sum[idx] = ws;
+    t.visit[idx] = n;
+  }
+  if (lane == 0) {
+    double ws = t.root_value_sum[b];
+    int n = t.root_visit[b];
+    for (int k = 0; k < wave; ++k) {
+      ws += root_add;
+      n += 1;
+      const double q = ws / (double)n;
+      lo = q < lo ? q : lo;
+      hi = q > hi ? q : hi;
+    }
+    t.root_value_sum[b] = ws;
+    t.root_visit[b] = n;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const double ol = shfl_xor_f64(lo, m), oh = shfl_xor_f64(hi, m);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if (lane == 0) {
+    const double plo = t.minmax[2 * b], phi = t.minmax[2 * b + 1];
+    t.minmax[2 * b] = lo < plo ? lo : plo;
+    t.minmax[2 * b + 1] = hi > phi ? hi : phi;
+  }
+}
+
+// ----------------------------------------------------------------- readout
+__global__ __launch_bounds__(kBlock) void readout_kernel(TreeView t, int* __restrict__ visits,
+                                                        double* __restrict__ root_value,
+                                                        double* __restrict__ probs) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (b >= t.B) return;
+  const int A = t.A;
+  const int n = lane < A ? t.visit[(size_t)b * t.N * A + lane] : 0;
+  int tot = n;
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) tot += __shfl_xor(tot, m);
+  if (lane < A) {
+    if (visits) visits[(size_t)b * A + lane] = n;
+    if (probs) probs[(size_t)b * A + lane] = tot == 0 ? 1.0 / (double)A : (double)n / (double)tot;
+  }
+  if (lane == 0 && root_value) {
+    const int rn = t.root_visit[b];
+    root_value[b] = rn == 0 ? 0.0 : t.root_value_sum[b] / (double)rn;
+  }
+}
+
+// ----------------------------------------------------------- select_action
+// One thread per game: the arithmetic is a short serial chain (cumulative sum).
+__device__ double numpy_pairwise_sum(const double* a, int n) {
+  // Order of additions of NumPy's float64 pairwise summation for n <= 128.
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+__global__ void select_action_kernel(const int* __restrict__ visits, int B, int A, double temperature,
+                                     const double* __restrict__ u, int* __restrict__ actions) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int* c = visits + (size_t)b * A;
+  if (temperature == 0.0) {
+    int best = 0;
+    for (int a = 1; a < A; ++a)
+      if (c[a] > c[best]) best = a;
+    actions[b] = best;
+    return;
+  }
+  double p[MZ_MAX_ACTIONS];
+  const double ex = 1.0 / temperature;
+  const int iex = (int)ex;
+  const bool integral = (double)iex == ex && iex >= 1 && iex <= 4;
+  for (int a = 0; a < A; ++a) {
+    const double x = (double)c[a];
+    double y;
+    if (integral) {
+      y = x;
+      for (int k = 1; k < iex; ++k) y *= x;
+    } else {
+      y = pow(x, ex);
+    }
+    p[a] = y;
+  }
+  // ndarray.sum(): the first element seeds the reduction, the rest is summed pairwise
+  const double tot = A > 1 ? p[0] + numpy_pairwise_sum(p + 1, A - 1) : p[0];
+  double run = 0.0;
+  for (int a = 0; a < A; ++a) {
+    run += p[a] / tot;
+    p[a] = run;
+  }
+  const double last = p[A - 1];
+  const double x = u[b];
+  int k = 0;
+  for (int a = 0; a < A; ++a) k += (p[a] / last) <= x;
+  actions[b] = k < A ? k : A - 1;
+}
+
+int blocks_for(int B) { return (B + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+int check_tree_args(const void* ws, const mz_tree_layout* L) {
+  MZ_REQUIRE(ws != nullptr && L != nullptr, "tree: null workspace or layout");
+  MZ_REQUIRE(L->B > 0 && L->A >= 1 && L->A <= MZ_MAX_ACTIONS && L->max_nodes >= 2,
+             "tree: bad layout (B=%d A=%d max_nodes=%d)", L->B, L->A, L->max_nodes);
+  return MZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_tree_layout_query(int32_t B, int32_t A, int32_t max_nodes, mz_tree_layout* out) {
+  MZ_REQUIRE(out != nullptr, "mz_tree_layout_query: out is null");
+  MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && max_nodes >= 2 && max_nodes <= 4096,
+             "mz_tree_layout_query: need B>0, 1<=A<=%d, 2<=max_nodes<=4096 (got %d, %d, %d)",
+             MZ_MAX_ACTIONS, B, A, max_nodes);
+  mz_tree_layout L{};
+  L.B = B; L.A = A; L.max_nodes = max_nodes;
+  int64_t off = 0;
+  auto take = [&off](int64_t bytes) {
+    int64_t at = off;
+    off += (bytes + 255) / 256 * 256;
+    return at;
+  };
+  const int64_t edges = (int64_t)B * max_nodes * A, nodes = (int64_t)B * max_nodes;
+  L.value_sum = take(edges * 8);
+  L.child = take(edges * 4);
+  L.visit = take(edges * 4);
+  L.prior = take(edges * 4);
+  L.root_prior64 = take((int64_t)B * A * 8);
+  L.reward = take(nodes * 8);
+  L.root_value_sum = take((int64_t)B * 8);
+  L.minmax = take((int64_t)B * 16);
+  L.num_nodes = take((int64_t)B * 4);
+  L.root_visit = take((int64_t)B * 4);
+  L.root_is_f64 = take((int64_t)B * 4);
+  L.path_node = take(nodes * 4);
+  L.path_action = take(nodes * 4);
+  L.path_len = take((int64_t)B * 4);
+  L.leaf_parent = take((int64_t)B * 4);
+  L.leaf_action = take((int64_t)B * 4);
+  L.status = take((int64_t)B * 4);
+  L.total_bytes = off;
+  *out = L;
+  return MZ_OK;
+}
+
+int mz_tree_root_init(void* ws, const mz_tree_layout* L, const float* priors, const double* noise,
+                      float keep_f32, double frac, mz_stream_t stream) {
+  if (int rc = check_tree_args(ws, L)) return rc;
+  MZ_REQUIRE(priors != nullptr, "mz_tree_root_init: priors is null");
+  TreeView t = make_view(ws, L);
+  hipLaunchKernelGGL(root_init_kernel, dim3(blocks_for(L->B)), dim3(kBlock), 0, mz::as_stream(stream), t,
+                     priors, noise, keep_f32, frac);
+  return mz::check_launch("mz_tree_root_init");
+}
+
+int mz_tree_select(void* ws, const mz_tree_layout* L, const double* pbc_table, const double* sqrt_table,
+                   int32_t table_len, mz_stream_t stream) {
+  if (int rc = check_tree_args(ws, L)) return rc;
+  MZ_REQUIRE(pbc_table && sqrt_table && table_len >= 2, "mz_tree_select: bad score tables");
+  TreeView t = make_view(ws, L);
+  hipLaunchKernelGGL(select_kernel, dim3(blocks_for(L->B)), dim3(kBlock), 0, mz::as_stream(stream), t,
+                     pbc_table, sqrt_table, table_len);
+  return mz::check_launch("mz_tree_select");
+}
+
+int mz_tree_expand_backup(void* ws, const mz_tree_layout* L, const float* priors, const float* value,
+                          const float* reward, int32_t wave, double gamma, mz_stream_t stream) {
+  if (int rc = check_tree_args(ws, L)) return rc;
+  MZ_REQUIRE(priors && value && reward, "mz_tree_expand_backup: null network output");
+  MZ_REQUIRE(wave >= 1, "mz_tree_expand_backup: wave must be >= 1 (got %d)", wave);
+  TreeView t = make_view(ws, L);
+  const size_t lds = (size_t)kWavesPerBlock * 2 * L->max_nodes * sizeof(double);
+  hipLaunchKernelGGL(expand_backup_kernel, dim3(blocks_for(L->B)), dim3(kBlock), lds, mz::as_stream(stream),
+                     t, priors, value, reward, wave, gamma);
+  return mz::check_launch("mz_tree_expand_backup");
+}
+
+int mz_tree_readout(const void* ws, const mz_tree_layout* L, int32_t* visits, double* root_value,
+                    double* probs, mz_stream_t stream) {
+  if (int rc = check_tree_args(ws, L)) return rc;
+  TreeView t = make_view(const_cast<void*>(ws), L);
+  hipLaunchKernelGGL(readout_kernel, dim3(blocks_for(L->B)), dim3(kBlock), 0, mz::as_stream(stream), t,
+                     visits, root_value, probs);
+  return mz::check_launch("mz_tree_readout");
+}
+
+int mz_select_action(const int32_t* visits, int32_t B, int32_t A, double temperature, const double* u,
+                     int32_t* actions, mz_stream_t stream) {
+  MZ_REQUIRE(visits && actions && B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS, "mz_select_action: bad arguments");
+  MZ_REQUIRE(temperature >= 0.0, "mz_select_action: negative temperature");
+  MZ_REQUIRE(temperature == 0.0 || u != nullptr, "mz_select_action: u is required when temperature > 0");
+  hipLaunchKernelGGL(select_action_kernel, dim3((B + 63) / 64), dim3(64), 0, mz::as_stream(stream), visits, B,
+                     A, temperature, u, actions);
+  return mz::check_launch("mz_select_action");
+}
+
+}  // extern "C"
