@@ -117,6 +117,85 @@ int mz_tree_readout(const void* ws, const mz_tree_layout* L, int32_t* visits,
 int mz_select_action(const int32_t* visits, int32_t B, int32_t A, double temperature,
                      const double* u, int32_t* actions, mz_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ * Networks.  Activations are NHWC; BatchNorm is applied in inference
+ * form (running statistics) folded into the convolution weights and
+ * bias by the host (model.py:143-175 blocks in eval mode).
+ * ------------------------------------------------------------------ */
+
+/* fp32 3x3 convolution, padding 1, stride 1 or 2, any shape: the validation
+ * precision of ResidualBlock / DownsampleBlock / conv_state (model.py:146-148,
+ * :165, :182, :213).  out = act(conv(x) + bias [+ residual]).
+ * w: float [9][Cin][Cout] (tap = ky*3+kx); bias float [Cout].
+ * in_slot (optional, int32 [B]): image b is read from image index
+ * in_slot[b] * slot_stride + b of `in` (gather of parent hidden states from
+ * the per-game node pool, replacing torch.cat at model.py:452).
+ * action_vec (optional, float [n_actions][Cin]) with actions int32 [B]:
+ * x = in + action_vec[actions[b]] inside the image before the convolution,
+ * which equals hidden + conv_action(one_hot planes) (model.py:231-236). */
+int mz_conv3x3_f32(const float* in, const int32_t* in_slot, int32_t slot_stride, const float* w,
+                   const float* bias, const float* residual, float* out, const float* action_vec,
+                   const int32_t* actions, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                   int32_t stride, int32_t relu, mz_stream_t stream);
+
+/* x.mean(dim=(2,3)) (model.py:243, :275): float NHWC [B][HW][C] -> [B][C]. */
+int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
+
+/* One fully connected head with a single hidden layer (model.py:217-224,
+ * :253-269): w1t float [C][Hd] and w2t float [Hd][O] are the TRANSPOSED
+ * torch Linear weights. */
+typedef struct mz_head_weights {
+  const float* w1t;
+  const float* b1;
+  const float* w2t;
+  const float* b2;
+} mz_head_weights;
+
+/* Policy, value and (optional) reward heads on the spatial mean [B][C], fused
+ * with what the search consumes: priors = softmax(policy logits)
+ * (model.py:397), value / reward = support_to_scalar(logits, S)
+ * (model.py:98-109, :399, :467).  Logit outputs ([B][A], [B][2S+1]) are optional
+ * (NULL = not written). reward_w == NULL (initial inference) skips the reward. */
+int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int32_t S,
+             const mz_head_weights* policy, const mz_head_weights* value_w, const mz_head_weights* reward_w,
+             float* priors, float* value, float* reward, float* policy_logits, float* value_logits,
+             float* reward_logits, mz_stream_t stream);
+
+/* support_to_scalar (model.py:98-109): float logits [n][2S+1] -> float [n]. */
+int mz_support_to_scalar(const float* logits, int32_t n, int32_t S, float* out, mz_stream_t stream);
+
+/* softmax(policy_logits, dim=1) as Node.expand applies it (model.py:397):
+ * float logits [n][A] -> float priors [n][A]; the same code the heads use. */
+int mz_policy_softmax(const float* logits, float* priors, int32_t n, int32_t A, mz_stream_t stream);
+
+/* Layout conversion between the reference's NCHW float tensors and NHWC. */
+int mz_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, mz_stream_t stream);
+int mz_nhwc_to_nchw_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, mz_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Frame-stack preprocessing (CustomFrameStack train.py:22-63,
+ * prepare_observation train.py:529-540).
+ * ------------------------------------------------------------------ */
+
+/* ring: uint8 [B][D][frame_bytes] device ring of the last D frames per game;
+ * frames: uint8 [B][frame_bytes] the new frame of every game (device memory,
+ * typically the target of a pinned async copy).  Writes slot `slot`, or every
+ * slot when fill_all != 0 (reset replicates the first frame, train.py:49-50). */
+int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int64_t frame_bytes, int32_t slot,
+                 int32_t fill_all, mz_stream_t stream);
+
+/* Stacked, normalised observation from the ring: out[b][pixel][age*3 + rgb] =
+ * frame(age)[pixel][rgb] / 255 with age 0 = oldest = slot (newest_slot+1) % D
+ * (train.py:62-63 then :534-540). out is NHWC, float32 or bf16 (out_is_bf16). */
+int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
+                   int32_t newest_slot, mz_stream_t stream);
+
+/* prepare_observation (train.py:529-540) for a batch: uint8 NHWC [B][HW][C]
+ * -> float32 NCHW [B][C][HW], x / 255 (bit-identical to the float64 divide
+ * followed by the float32 cast for all 256 byte values). */
+int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,
+                           mz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,16 @@ _SIGNATURES = {
     "mz_tree_expand_backup": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P]),
     "mz_tree_readout": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, _P]),
     "mz_select_action": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
+    "mz_conv3x3_f32": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
+    "mz_spatial_mean_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_heads": (C.c_int, [_P] + [C.c_int32] * 5 + [_P] * 10),
+    "mz_support_to_scalar": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "mz_policy_softmax": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P]),
+    "mz_nchw_to_nhwc_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_nhwc_to_nchw_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_ring_push": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "mz_ring_to_obs": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 
 _lib = None

@@ -1,0 +1,368 @@
+// fp32 network kernels: the validation-precision path (exact float32
+// arithmetic, any layer shape) plus the pieces both precisions share
+// (spatial mean, prediction / reward heads with fused softmax and support
+// decode, layout conversion).  Activations are NHWC.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------ conv3x3, fp32
+// One block = TP consecutive output pixels of one output row x all Cout
+// channels; thread c owns output channel c.  The 3 x (TP*stride+2) input
+// window is staged in LDS (zero outside the image), so every weight that a
+// thread loads is reused TP times and every activation read is an LDS
+// broadcast.  Weights are [tap][cin][cout] so the per-thread loads coalesce.
+constexpr int TP = 4;
+
+__global__ void conv3x3_f32_kernel(const float* __restrict__ in, const int* __restrict__ in_slot, int slot_stride,
+                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                   const float* __restrict__ residual, float* __restrict__ out,
+                                   const float* __restrict__ avec, const int* __restrict__ actions, int H, int W,
+                                   int Cin, int Cout, int stride, int HO, int WO, int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);  // [3][TW][Cin]
+  const int TW = TP * stride + 2;
+  const int b = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * TP;
+  const int c = threadIdx.x;
+  const long img = in_slot ? (long)in_slot[b] * slot_stride + b : b;
+  const float* src = in + img * (long)H * W * Cin;
+  const float* av = avec ? avec + (long)actions[b] * Cin : nullptr;
+  const int iy0 = oy * stride - 1, ix0 = ox0 * stride - 1;
+  for (int i = threadIdx.x; i < 3 * TW * Cin; i += blockDim.x) {
+    const int ci = i % Cin, px = (i / Cin) % TW, py = i / (Cin * TW);
+    const int iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      v = src[((long)iy * W + ix) * Cin + ci];
+      if (av) v += av[ci];  // hidden + conv1x1(one-hot action) inside the image only (model.py:236)
+    }
+    tile[i] = v;
+  }
+  __syncthreads();
+  if (c >= Cout) return;
+  float acc[TP];
+#pragma unroll
+  for (int p = 0; p < TP; ++p) acc[p] = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+    const float* wt = w + (long)tap * Cin * Cout + c;
+    const float* trow = tile + (dy * TW + dx) * Cin;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float wv = wt[(long)ci * Cout];
+#pragma unroll
+      for (int p = 0; p < TP; ++p) acc[p] = fmaf(trow[p * stride * Cin + ci], wv, acc[p]);
+    }
+  }
+  const float bv = bias[c];
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const long o = (((long)b * HO + oy) * WO + ox0 + p) * Cout + c;
+    float v = acc[p] + bv;
+    if (residual) v += residual[o];
+    if (relu) v = fmaxf(v, 0.f);
+    out[o] = v;
+  }
+}
+
+// -------------------------------------------------------------- spatial mean
+__global__ void spatial_mean_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float* p = in + (long)b * HW * C + c;
+    float s = 0.f;
+    for (int i = 0; i < HW; ++i) s += p[(long)i * C];
+    out[(long)b * C + c] = s / (float)HW;
+  }
+}
+
+// --------------------------------------------------------------------- heads
+// Policy / value / reward MLPs (one hidden layer each) on the spatial mean,
+// with the softmax over actions and the support decode fused
+// (model.py:243, :275-280, :397, :89-109).  One block handles HS samples so a
+// weight read from L2 is used HS times.
+constexpr int HS = 4;
+constexpr int kHeadsBlock = 256;
+
+struct HeadW {
+  const float* w1t;  // [C][Hd]   (transposed Linear weight)
+  const float* b1;   // [Hd]
+  const float* w2t;  // [Hd][O]
+  const float* b2;   // [O]
+};
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  // red: kHeadsBlock/64 floats of LDS scratch
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const float o = __shfl_xor(v, m);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kHeadsBlock / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+
+// softmax over the (up to 64) logits held one per lane of a wavefront
+__device__ __forceinline__ float wave_softmax(float lg, bool active) {
+  float m = active ? lg : -__builtin_inff();
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+  const float e = active ? expf(lg - m) : 0.f;
+  float den = e;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) den += __shfl_xor(den, k);
+  return e / den;
+}
+
+// float32 operation sequence of inverse_transform_value (model.py:93-95);
+// contraction is off so that no multiply-add is fused.
+__device__ float inverse_value_transform(float x) {
+#pragma clang fp contract(off)
+  const float eps = 0.001f;
+  float t = fabsf(x) + 1.0f;
+  t = t + eps;
+  t = 0.004f * t;
+  t = 1.0f + t;
+  t = sqrtf(t) - 1.0f;
+  t = t / 0.002f;
+  t = t * t - 1.0f;
+  const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+  return sg * t;
+}
+
+// hidden layer for one head: hid[s][j] = relu(b1[j] + sum_k mean[s][k] * w1t[k][j])
+__device__ void head_hidden(const HeadW& hw, const float* mean_s, float* hid_s, int C, int Hd, int ns) {
+  for (int j = threadIdx.x; j < Hd; j += kHeadsBlock) {
+    float a[HS];
+#pragma unroll
+    for (int s = 0; s < HS; ++s) a[s] = hw.b1[j];
+    for (int k = 0; k < C; ++k) {
+      const float wv = hw.w1t[(long)k * Hd + j];
+#pragma unroll
+      for (int s = 0; s < HS; ++s) a[s] = fmaf(mean_s[s * C + k], wv, a[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < HS; ++s) hid_s[s * Hd + j] = fmaxf(a[s], 0.f);
+  }
+}
+
+// output layer into LDS logits[s][o]
+__device__ void head_out(const HeadW& hw, const float* hid_s, float* logit_s, int Hd, int O, int ldo) {
+  for (int o = threadIdx.x; o < O; o += kHeadsBlock) {
+    float a[HS];
+#pragma unroll
+    for (int s = 0; s < HS; ++s) a[s] = hw.b2[o];
+    for (int k = 0; k < Hd; ++k) {
+      const float wv = hw.w2t[(long)k * O + o];
+#pragma unroll
+      for (int s = 0; s < HS; ++s) a[s] = fmaf(hid_s[s * Hd + k], wv, a[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < HS; ++s) logit_s[s * ldo + o] = a[s];
+  }
+}
+
+// softmax expectation over bins -S..S of logits[0..O), then the inverse transform
+__device__ float decode_support(const float* lg, int O, float* red) {
+  const int S = O / 2;
+  float m = -__builtin_inff();
+  for (int o = threadIdx.x; o < O; o += kHeadsBlock) m = fmaxf(m, lg[o]);
+  m = block_reduce(m, red, true);
+  float den = 0.f, num = 0.f;
+  for (int o = threadIdx.x; o < O; o += kHeadsBlock) {
+    const float e = expf(lg[o] - m);
+    den += e;
+    num += e * (float)(o - S);
+  }
+  den = block_reduce(den, red, false);
+  num = block_reduce(num, red, false);
+  return inverse_value_transform(num / den);
+}
+
+__global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
+    const float* __restrict__ mean, int B, int C, int Hd, int A, int O, HeadW pol, HeadW val, HeadW rew,
+    int with_reward, float* __restrict__ priors, float* __restrict__ value, float* __restrict__ reward,
+    float* __restrict__ policy_logits, float* __restrict__ value_logits, float* __restrict__ reward_logits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* mean_s = reinterpret_cast<float*>(smem);  // [HS][C]
+  float* hid_s = mean_s + HS * C;                  // [HS][Hd]
+  float* logit_s = hid_s + HS * Hd;                // [HS][ldo]
+  float* red = logit_s + HS * (O > A ? O : A);     // [4]
+  const int ldo = O > A ? O : A;
+  const int b0 = blockIdx.x * HS;
+  const int ns = B - b0 < HS ? B - b0 : HS;
+  for (int i = threadIdx.x; i < HS * C; i += kHeadsBlock) {
+    const int s = i / C;
+    mean_s[i] = s < ns ? mean[(long)(b0 + s) * C + (i % C)] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- policy: logits -> softmax priors
+  head_hidden(pol, mean_s, hid_s, C, Hd, ns);
+  __syncthreads();
+  head_out(pol, hid_s, logit_s, Hd, A, ldo);
+  __syncthreads();
+  if (threadIdx.x < HS * 64) {  // one wavefront per sample, A <= 64
+    const int s = threadIdx.x >> 6, a = threadIdx.x & 63;
+    const float lg = a < A ? logit_s[s * ldo + a] : -__builtin_inff();
+    const float pr = wave_softmax(lg, a < A);
+    if (s < ns && a < A) {
+      priors[(long)(b0 + s) * A + a] = pr;
+      if (policy_logits) policy_logits[(long)(b0 + s) * A + a] = lg;
+    }
+  }
+  __syncthreads();
+
+  // ---- value and (optionally) reward: logits -> decoded scalar
+  for (int h = 0; h < (with_reward ? 2 : 1); ++h) {
+    const HeadW& hw = h == 0 ? val : rew;
+    float* dst = h == 0 ? value : reward;
+    float* lg_out = h == 0 ? value_logits : reward_logits;
+    head_hidden(hw, mean_s, hid_s, C, Hd, ns);
+    __syncthreads();
+    head_out(hw, hid_s, logit_s, Hd, O, ldo);
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+      const float y = decode_support(logit_s + s * ldo, O, red);
+      if (threadIdx.x == 0) dst[b0 + s] = y;
+      if (lg_out)
+        for (int o = threadIdx.x; o < O; o += kHeadsBlock) lg_out[(long)(b0 + s) * O + o] = logit_s[s * ldo + o];
+    }
+    __syncthreads();
+  }
+}
+
+// decode only: logits [n][O] -> scalar [n]  (support_to_scalar, model.py:98-109)
+__global__ __launch_bounds__(kHeadsBlock) void decode_kernel(const float* __restrict__ logits, int O,
+                                                             float* __restrict__ out) {
+  __shared__ float red[kHeadsBlock / 64];
+  const float y = decode_support(logits + (long)blockIdx.x * O, O, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = y;
+}
+
+// softmax(policy_logits, dim=1) (model.py:397): one wavefront per row
+__global__ void policy_softmax_kernel(const float* __restrict__ logits, float* __restrict__ priors, int n, int A) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), a = threadIdx.x & 63;
+  if (row >= n) return;
+  const float lg = a < A ? logits[(long)row * A + a] : 0.f;
+  const float pr = wave_softmax(lg, a < A);
+  if (a < A) priors[(long)row * A + a] = pr;
+}
+
+// ------------------------------------------------------- layout conversions
+// NCHW f32 -> NHWC f32 (tile transpose through LDS so both sides coalesce)
+__global__ void nchw_to_nhwc_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    t[r][tx] = (c < C && p < HW) ? in[((long)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    if (c < C && p < HW) out[((long)b * HW + p) * C + c] = t[tx][r];
+  }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    t[r][tx] = (c < C && p < HW) ? in[((long)b * HW + p) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) out[((long)b * C + c) * HW + p] = t[tx][r];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_conv3x3_f32(const float* in, const int32_t* in_slot, int32_t slot_stride, const float* w,
+                   const float* bias, const float* residual, float* out, const float* action_vec,
+                   const int32_t* actions, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                   int32_t stride, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(in && w && bias && out, "mz_conv3x3_f32: null tensor");
+  MZ_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= 1024, "mz_conv3x3_f32: bad shape");
+  MZ_REQUIRE(stride == 1 || stride == 2, "mz_conv3x3_f32: stride must be 1 or 2");
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv3x3_f32: action_vec and actions go together");
+  const int HO = (H + 2 - 3) / stride + 1, WO = (W + 2 - 3) / stride + 1;
+  MZ_REQUIRE(WO % TP == 0, "mz_conv3x3_f32: output width %d must be a multiple of %d", WO, TP);
+  MZ_REQUIRE(B <= 65535, "mz_conv3x3_f32: batch %d exceeds the grid limit", B);
+  const size_t lds = (size_t)3 * (TP * stride + 2) * Cin * sizeof(float);
+  MZ_REQUIRE(lds <= 64 * 1024, "mz_conv3x3_f32: Cin %d too large for the LDS window", Cin);
+  const int threads = (Cout + 63) / 64 * 64;
+  hipLaunchKernelGGL(conv3x3_f32_kernel, dim3(WO / TP, HO, B), dim3(threads), lds, mz::as_stream(stream), in,
+                     in_slot, slot_stride, w, bias, residual, out, action_vec, actions, H, W, Cin, Cout, stride,
+                     HO, WO, relu);
+  return mz::check_launch("mz_conv3x3_f32");
+}
+
+int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream) {
+  MZ_REQUIRE(in && out && B > 0 && HW > 0 && C > 0, "mz_spatial_mean_f32: bad arguments");
+  hipLaunchKernelGGL(spatial_mean_f32_kernel, dim3(B), dim3(256), 0, mz::as_stream(stream), in, out, HW, C);
+  return mz::check_launch("mz_spatial_mean_f32");
+}
+
+int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int32_t S,
+             const mz_head_weights* policy, const mz_head_weights* value_w, const mz_head_weights* reward_w,
+             float* priors, float* value, float* reward, float* policy_logits, float* value_logits,
+             float* reward_logits, mz_stream_t stream) {
+  MZ_REQUIRE(mean && policy && value_w && priors && value, "mz_heads: null argument");
+  MZ_REQUIRE((reward_w == nullptr) == (reward == nullptr), "mz_heads: reward weights and output go together");
+  MZ_REQUIRE(B > 0 && C > 0 && Hd > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && S >= 1, "mz_heads: bad sizes");
+  const int O = 2 * S + 1;
+  const int ldo = O > A ? O : A;
+  const size_t lds = (size_t)(HS * C + HS * Hd + HS * ldo + kHeadsBlock / 64) * sizeof(float);
+  MZ_REQUIRE(lds <= 64 * 1024, "mz_heads: layer sizes exceed the LDS budget");
+  auto cvt = [](const mz_head_weights* h) {
+    HeadW r{nullptr, nullptr, nullptr, nullptr};
+    if (h) r = HeadW{h->w1t, h->b1, h->w2t, h->b2};
+    return r;
+  };
+  hipLaunchKernelGGL(heads_kernel, dim3((B + HS - 1) / HS), dim3(kHeadsBlock), lds, mz::as_stream(stream), mean,
+                     B, C, Hd, A, O, cvt(policy), cvt(value_w), cvt(reward_w), reward_w ? 1 : 0, priors, value,
+                     reward, policy_logits, value_logits, reward_logits);
+  return mz::check_launch("mz_heads");
+}
+
+int mz_support_to_scalar(const float* logits, int32_t n, int32_t S, float* out, mz_stream_t stream) {
+  MZ_REQUIRE(logits && out && n > 0 && S >= 1, "mz_support_to_scalar: bad arguments");
+  hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(kHeadsBlock), 0, mz::as_stream(stream), logits, 2 * S + 1, out);
+  return mz::check_launch("mz_support_to_scalar");
+}
+
+int mz_policy_softmax(const float* logits, float* priors, int32_t n, int32_t A, mz_stream_t stream) {
+  MZ_REQUIRE(logits && priors && n > 0 && A >= 1 && A <= MZ_MAX_ACTIONS, "mz_policy_softmax: bad arguments");
+  hipLaunchKernelGGL(policy_softmax_kernel, dim3((n + 3) / 4), dim3(256), 0, mz::as_stream(stream), logits, priors,
+                     n, A);
+  return mz::check_launch("mz_policy_softmax");
+}
+
+int mz_nchw_to_nhwc_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, mz_stream_t stream) {
+  MZ_REQUIRE(in && out && B > 0 && C > 0 && HW > 0 && B <= 65535, "mz_nchw_to_nhwc_f32: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                     mz::as_stream(stream), in, out, C, HW);
+  return mz::check_launch("mz_nchw_to_nhwc_f32");
+}
+
+int mz_nhwc_to_nchw_f32(const float* in, float* out, int32_t B, int32_t C, int32_t HW, mz_stream_t stream) {
+  MZ_REQUIRE(in && out && B > 0 && C > 0 && HW > 0 && B <= 65535, "mz_nhwc_to_nchw_f32: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                     mz::as_stream(stream), in, out, C, HW);
+  return mz::check_launch("mz_nhwc_to_nchw_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Frame-stack preprocessing on the device: a ring of the last D frames per
+// game (CustomFrameStack, train.py:22-63) and the normalised network input
+// (prepare_observation, train.py:529-540).  Only the newest 96x96x3 frame of
+// each game has to cross PCIe per environment step.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+  unsigned int u = __float_as_uint(f);  // finite, non-negative inputs only
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ring [B][D][frame_bytes]; frames [B][frame_bytes].  fill_all != 0 copies the
+// frame into every slot (the reset rule, train.py:49-50).
+__global__ void ring_push_kernel(unsigned char* __restrict__ ring, const unsigned char* __restrict__ frames,
+                                 int D, long frame_bytes, int slot, int fill_all) {
+  const int b = blockIdx.y;
+  const uint4* src = reinterpret_cast<const uint4*>(frames + (long)b * frame_bytes);
+  const long n16 = frame_bytes / 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const uint4 v = src[i];
+    if (fill_all) {
+      for (int d = 0; d < D; ++d) reinterpret_cast<uint4*>(ring + ((long)b * D + d) * frame_bytes)[i] = v;
+    } else {
+      reinterpret_cast<uint4*>(ring + ((long)b * D + slot) * frame_bytes)[i] = v;
+    }
+  }
+}
+
+// One block = 64 pixels of one game: the 64*3 bytes of every frame are staged in
+// LDS, then written as [pixel][3*D] with channel = age_rank*3 + rgb, oldest frame
+// first (train.py:62-63), normalised by /255 in float32 (bit-identical to the
+// reference's float64 divide + float32 cast for every byte value).
+constexpr int kPix = 64;
+template <typename OutT>
+__global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* __restrict__ ring,
+                                                         OutT* __restrict__ out, int D, int HW, int newest) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned char* st = reinterpret_cast<unsigned char*>(smem);  // [D][kPix*3]
+  const int b = blockIdx.y, p0 = blockIdx.x * kPix;
+  const int np = HW - p0 < kPix ? HW - p0 : kPix;
+  const int row = kPix * 3;
+  for (int i = threadIdx.x; i < D * row; i += blockDim.x) {
+    const int f = i / row, o = i % row;
+    const int slot = (newest + 1 + f) % D;
+    st[i] = o < np * 3 ? ring[(((long)b * D + slot) * HW + p0) * 3 + o] : 0;
+  }
+  __syncthreads();
+  const int C = 3 * D;
+  for (int i = threadIdx.x; i < np * C; i += blockDim.x) {
+    const int px = i / C, c = i % C;
+    const float v = (float)st[(c / 3) * row + px * 3 + (c % 3)] / 255.0f;
+    const long o = ((long)b * HW + p0 + px) * C + c;
+    if constexpr (sizeof(OutT) == 2) out[o] = f32_to_bf16_rne(v);
+    else out[o] = v;
+  }
+}
+
+// uint8 NHWC [B][HW][C] -> float32 NCHW [B][C][HW], x / 255 (train.py:534-540)
+__global__ void prepare_observation_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int C,
+                                           int HW) {
+  __shared__ unsigned char t[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    t[r][tx] = (c < C && p < HW) ? in[((long)b * HW + p) * C + c] : 0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) out[((long)b * C + c) * HW + p] = (float)t[tx][r] / 255.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int64_t frame_bytes, int32_t slot,
+                 int32_t fill_all, mz_stream_t stream) {
+  MZ_REQUIRE(ring && frames && B > 0 && D > 0 && B <= 65535, "mz_ring_push: bad arguments");
+  MZ_REQUIRE(frame_bytes > 0 && frame_bytes % 16 == 0, "mz_ring_push: frame_bytes must be a multiple of 16");
+  MZ_REQUIRE(slot >= 0 && slot < D, "mz_ring_push: slot %d outside ring of depth %d", slot, D);
+  const int blocks = (int)((frame_bytes / 16 + 255) / 256);
+  hipLaunchKernelGGL(ring_push_kernel, dim3(blocks, B), dim3(256), 0, mz::as_stream(stream), ring, frames, D,
+                     (long)frame_bytes, slot, fill_all);
+  return mz::check_launch("mz_ring_push");
+}
+
+int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
+                   int32_t newest_slot, mz_stream_t stream) {
+  MZ_REQUIRE(ring && out && B > 0 && D > 0 && HW > 0 && B <= 65535, "mz_ring_to_obs: bad arguments");
+  MZ_REQUIRE(newest_slot >= 0 && newest_slot < D, "mz_ring_to_obs: newest_slot outside the ring");
+  const size_t lds = (size_t)D * kPix * 3;
+  MZ_REQUIRE(lds <= 64 * 1024, "mz_ring_to_obs: ring depth %d too large", D);
+  const dim3 grid((HW + kPix - 1) / kPix, B);
+  if (out_is_bf16)
+    hipLaunchKernelGGL(ring_to_obs_kernel<unsigned short>, grid, dim3(256), lds, mz::as_stream(stream), ring,
+                       static_cast<unsigned short*>(out), D, HW, newest_slot);
+  else
+    hipLaunchKernelGGL(ring_to_obs_kernel<float>, grid, dim3(256), lds, mz::as_stream(stream), ring,
+                       static_cast<float*>(out), D, HW, newest_slot);
+  return mz::check_launch("mz_ring_to_obs");
+}
+
+int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,
+                           mz_stream_t stream) {
+  MZ_REQUIRE(obs_nhwc && out_nchw && B > 0 && C > 0 && HW > 0 && B <= 65535, "mz_prepare_observation: bad arguments");
+  hipLaunchKernelGGL(prepare_observation_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                     mz::as_stream(stream), obs_nhwc, out_nchw, C, HW);
+  return mz::check_launch("mz_prepare_observation");
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+"""The representation / dynamics / prediction networks on HIP kernels, behind the
+reference's call surface (model.py:284-348).
+
+``MuZeroNetwork(config).initial_inference(obs)`` and
+``.recurrent_inference(hidden, action)`` take and return the reference's NCHW
+float32 tensors.  The search driver (``muzero_amd.search``) uses the
+``*_to_pool`` methods instead, which keep hidden states in a device pool in the
+kernels' own NHWC layout and return only what the tree consumes (softmax priors,
+decoded value and reward).
+
+Inference semantics: BatchNorm uses its running statistics (eval mode), folded
+into the convolution weights when a ``state_dict`` is loaded.  Parameter names
+are the reference's, so a reference checkpoint's ``model_state_dict`` loads
+directly.
+
+Precisions: ``"fp32"`` - exact float32 kernels for any layer shape (validation);
+``"bf16"`` - bf16 MFMA kernels with float32 accumulation for the reference's
+default architecture (throughput).
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+
+class NetworkOutput:
+    """Same fields and helpers as model.py:284-304."""
+
+    def __init__(self, value, reward, policy_logits, hidden_state):
+        self.value = value
+        self.reward = reward
+        self.policy_logits = policy_logits
+        self.hidden_state = hidden_state
+
+    def scalar_value(self) -> float:
+        return support_to_scalar(self.value, self.value.shape[-1] // 2).item()
+
+    def scalar_reward(self) -> Optional[float]:
+        if self.reward is None:
+            return None
+        return support_to_scalar(self.reward, self.reward.shape[-1] // 2).item()
+
+
+def support_to_scalar(logits: torch.Tensor, support_size: int) -> torch.Tensor:
+    """model.py:98-109 on the device: float32 logits [n, 2S+1] -> float32 [n]."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] == 2 * support_size + 1
+    logits = logits.contiguous()
+    out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    _lib.call("mz_support_to_scalar", _lib.ptr(logits), logits.shape[0], support_size, _lib.ptr(out),
+              _lib.current_stream())
+    return out
+
+
+# --------------------------------------------------------------------------- weights
+def init_state_dict(cfg, seed: int = 0, randomize_bn: bool = False) -> "OrderedDict[str, torch.Tensor]":
+    """Random parameters with the reference's names and shapes (torch default
+    initialisation laws: U(+-1/sqrt(fan_in)) for conv / linear weights and biases,
+    identity BatchNorm).  ``randomize_bn`` draws non-trivial BatchNorm statistics so
+    that folding is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def uni(shape, fan_in):
+        k = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * k
+
+    def conv(name, cin, cout, ks=3):
+        sd[name + ".weight"] = uni((cout, cin, ks, ks), cin * ks * ks)
+        sd[name + ".bias"] = uni((cout,), cin * ks * ks)
+
+    def bn(name, c):
+        if randomize_bn:
+            sd[name + ".weight"] = torch.rand(c, generator=g) * 0.5 + 0.75
+            sd[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+            sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+            sd[name + ".running_var"] = torch.rand(c, generator=g) + 0.5
+        else:
+            sd[name + ".weight"] = torch.ones(c)
+            sd[name + ".bias"] = torch.zeros(c)
+            sd[name + ".running_mean"] = torch.zeros(c)
+            sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def res(name, c):
+        conv(name + ".conv1", c, c); bn(name + ".bn1", c)
+        conv(name + ".conv2", c, c); bn(name + ".bn2", c)
+
+    def mlp(name, cin, hidden, cout):
+        i = 0
+        for h in hidden:
+            sd[f"{name}.{i}.weight"] = uni((h, cin), cin)
+            sd[f"{name}.{i}.bias"] = uni((h,), cin)
+            cin = h
+            i += 2
+        sd[f"{name}.{i}.weight"] = uni((cout, cin), cin)
+        sd[f"{name}.{i}.bias"] = uni((cout,), cin)
+
+    W, A, S = cfg.num_channels, cfg.action_space_size, cfg.support_size
+    conv("representation.conv1", cfg.observation_shape[0], W); bn("representation.bn1", W)
+    c = W
+    for i, (cout, n) in enumerate(cfg.downsample_steps):
+        conv(f"representation.downsample.{i}.conv", c, cout); bn(f"representation.downsample.{i}.bn", cout)
+        for j in range(n):
+            res(f"representation.downsample.{i}.blocks.{j}", cout)
+        c = cout
+    for j in range(6):
+        res(f"representation.resblocks.{j}", c)
+    conv("dynamics.conv_action", A, W, 1)
+    conv("dynamics.conv_state", W, W); bn("dynamics.bn", W)
+    for j in range(cfg.num_blocks):
+        res(f"dynamics.resblocks.{j}", W)
+    mlp("dynamics.reward_head", W, cfg.fc_reward_layers, 2 * S + 1)
+    mlp("prediction.policy_head", W, cfg.fc_policy_layers, A)
+    mlp("prediction.value_head", W, cfg.fc_value_layers, 2 * S + 1)
+    return sd
+
+
+class ConvLayer:
+    """One 3x3 convolution with BatchNorm folded in (float32 master copy)."""
+
+    def __init__(self, sd, conv: str, bn: str, stride: int):
+        w = sd[conv + ".weight"].double()
+        b = sd[conv + ".bias"].double()
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
+        self.w = (w * scale.view(-1, 1, 1, 1)).float()                       # [Cout][Cin][3][3]
+        self.b = ((b - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()).float()
+        self.cout, self.cin = self.w.shape[0], self.w.shape[1]
+        self.stride = stride
+        self.name = conv
+        self.dev: Dict[str, torch.Tensor] = {}
+
+
+class Head:
+    def __init__(self, sd, name: str, device):
+        keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
+        if len(keys) != 2:
+            raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
+        k1, k2 = keys
+        self.w1t = sd[f"{name}.{k1}.weight"].float().t().contiguous().to(device)
+        self.b1 = sd[f"{name}.{k1}.bias"].float().contiguous().to(device)
+        self.w2t = sd[f"{name}.{k2}.weight"].float().t().contiguous().to(device)
+        self.b2 = sd[f"{name}.{k2}.bias"].float().contiguous().to(device)
+        self.hidden = self.w1t.shape[1]
+        self.out = self.w2t.shape[1]
+        self.c = _HeadWeights(self.w1t.data_ptr(), self.b1.data_ptr(), self.w2t.data_ptr(), self.b2.data_ptr())
+
+
+class _HeadWeights(C.Structure):
+    _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p)]
+
+
+# --------------------------------------------------------------------------- network
+class MuZeroNetwork:
+    def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        _lib.lib()  # fail now, loudly, if the HIP library is missing
+        self.config = config
+        self.precision = precision
+        self.device = torch.device(device)
+        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.A = config.action_space_size
+        self.S = config.support_size
+        self.W = config.num_channels
+        self.cin = config.observation_shape[0]
+        self._buffers: Dict[tuple, torch.Tensor] = {}
+        self.load_state_dict(state_dict if state_dict is not None else init_state_dict(config, seed))
+
+    # ---- parameters
+    def load_state_dict(self, sd) -> None:
+        sd = {k: v.detach().cpu() for k, v in sd.items()}
+        self._state_dict = sd
+        cfg = self.config
+        rep: List[tuple] = [("conv", ConvLayer(sd, "representation.conv1", "representation.bn1", 2))]
+        for i, (_, n) in enumerate(cfg.downsample_steps):
+            p = f"representation.downsample.{i}"
+            rep.append(("conv", ConvLayer(sd, p + ".conv", p + ".bn", 2)))
+            for j in range(n):
+                rep.append(("res", self._res(sd, f"{p}.blocks.{j}")))
+        j = 0
+        while f"representation.resblocks.{j}.conv1.weight" in sd:
+            rep.append(("res", self._res(sd, f"representation.resblocks.{j}")))
+            j += 1
+        self.rep_plan = rep
+        self.dyn_first = ConvLayer(sd, "dynamics.conv_state", "dynamics.bn", 1)
+        self.dyn_blocks = [self._res(sd, f"dynamics.resblocks.{j}") for j in range(cfg.num_blocks)]
+        wa = sd["dynamics.conv_action.weight"].float()[:, :, 0, 0]          # [W][A]
+        self.action_vec = (wa.t() + sd["dynamics.conv_action.bias"].float()).contiguous().to(self.device)  # [A][W]
+        self.policy = Head(sd, "prediction.policy_head", self.device)
+        self.value_head = Head(sd, "prediction.value_head", self.device)
+        self.reward_head = Head(sd, "dynamics.reward_head", self.device)
+        if not (self.policy.hidden == self.value_head.hidden == self.reward_head.hidden):
+            raise NotImplementedError("the three heads must share one hidden width")
+        for layer in self.all_convs():
+            self._upload(layer)
+
+    def state_dict(self):
+        return self._state_dict
+
+    @staticmethod
+    def _res(sd, p):
+        return (ConvLayer(sd, p + ".conv1", p + ".bn1", 1), ConvLayer(sd, p + ".conv2", p + ".bn2", 1))
+
+    def all_convs(self):
+        for kind, item in self.rep_plan:
+            yield from ([item] if kind == "conv" else item)
+        yield self.dyn_first
+        for blk in self.dyn_blocks:
+            yield from blk
+
+    def _upload(self, layer: ConvLayer) -> None:
+        layer.dev["bias"] = layer.b.contiguous().to(self.device)
+        if self.precision == "fp32":
+            # [Cout][Cin][ky][kx] -> [tap][Cin][Cout]
+            layer.dev["w"] = layer.w.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device)
+        else:
+            from . import mfma
+            layer.dev["w"] = mfma.pack_weights(layer.w).to(self.device)
+
+    # ---- scratch
+    def _buf(self, tag, shape, dtype=None):
+        dtype = dtype or self.act_dtype
+        key = (tag, tuple(shape), dtype)
+        t = self._buffers.get(key)
+        if t is None:
+            t = torch.empty(*shape, dtype=dtype, device=self.device)
+            self._buffers[key] = t
+        return t
+
+    # ---- kernels
+    def _conv(self, layer: ConvLayer, x, out, H, W, relu=True, residual=None, in_slot=None, slot_stride=0,
+              actions=None, mean_out=None):
+        B = out.shape[0]
+        if self.precision == "fp32":
+            _lib.call("mz_conv3x3_f32", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(layer.dev["w"]),
+                      _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out),
+                      _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
+                      B, H, W, layer.cin, layer.cout, layer.stride, 1 if relu else 0, _lib.current_stream())
+            if mean_out is not None:
+                HO = (H - 1) // layer.stride + 1
+                WO = (W - 1) // layer.stride + 1
+                _lib.call("mz_spatial_mean_f32", _lib.ptr(out), _lib.ptr(mean_out), B, HO * WO, layer.cout,
+                          _lib.current_stream())
+        else:
+            from . import mfma
+            mfma.conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride,
+                      self.action_vec if actions is not None else None, actions, mean_out)
+
+    def _res_block(self, blk, x, tmp, out, H, W, mean_out=None):
+        """out = relu(conv2(relu(conv1(x))) + x); out may alias nothing but x's pool slot."""
+        self._conv(blk[0], x, tmp, H, W, relu=True)
+        self._conv(blk[1], tmp, out, H, W, relu=True, residual=x, mean_out=mean_out)
+
+    def _heads(self, mean, B, with_reward: bool, want_logits: bool):
+        dev = self.device
+        O = 2 * self.S + 1
+        priors = torch.empty(B, self.A, dtype=torch.float32, device=dev)
+        value = torch.empty(B, dtype=torch.float32, device=dev)
+        reward = torch.empty(B, dtype=torch.float32, device=dev) if with_reward else None
+        pl = torch.empty(B, self.A, dtype=torch.float32, device=dev) if want_logits else None
+        vl = torch.empty(B, O, dtype=torch.float32, device=dev) if want_logits else None
+        rl = torch.empty(B, O, dtype=torch.float32, device=dev) if (want_logits and with_reward) else None
+        _lib.call("mz_heads", _lib.ptr(mean), B, self.W, self.policy.hidden, self.A, self.S,
+                  C.byref(self.policy.c), C.byref(self.value_head.c),
+                  C.byref(self.reward_head.c) if with_reward else None,
+                  _lib.ptr(priors), _lib.ptr(value), _lib.ptr(reward), _lib.ptr(pl), _lib.ptr(vl), _lib.ptr(rl),
+                  _lib.current_stream())
+        return priors, value, reward, pl, vl, rl
+
+    # ---- representation / dynamics on NHWC activations
+    def hidden_hw(self, H: int, W: int):
+        n = 1 + len(self.config.downsample_steps)
+        for _ in range(n):
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        return H, W
+
+    def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
+        """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W]."""
+        B, H, W, _ = obs_nhwc.shape
+        x = obs_nhwc
+        last = len(self.rep_plan) - 1
+        for i, (kind, item) in enumerate(self.rep_plan):
+            if kind == "conv":
+                HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+                y = hidden_out if i == last else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
+                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if i == last else None)
+                x, H, W = y, HO, WO
+            else:
+                c = item[0].cout
+                tmp = self._buf(("rep_tmp", H), (B, H, W, c))
+                y = hidden_out if i == last else self._buf(("rep", i % 3), (B, H, W, c))
+                self._res_block(item, x, tmp, y, H, W, mean_out=mean_out if i == last else None)
+                x = y
+
+    def dynamics(self, pool: torch.Tensor, in_slot: Optional[torch.Tensor], slot_stride: int,
+                 actions: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
+        """hidden' = dynamics(pool[in_slot[b]*slot_stride + b], actions[b]) for every b."""
+        B, H, W, c = hidden_out.shape
+        a = self._buf("dyn_a", (B, H, W, c))
+        t = self._buf("dyn_t", (B, H, W, c))
+        cur, spare = a, self._buf("dyn_b", (B, H, W, c))
+        n = len(self.dyn_blocks)
+        first_out = hidden_out if n == 0 else cur
+        self._conv(self.dyn_first, pool, first_out, H, W, relu=True, in_slot=in_slot, slot_stride=slot_stride,
+                   actions=actions, mean_out=mean_out if n == 0 else None)
+        for j, blk in enumerate(self.dyn_blocks):
+            y = hidden_out if j == n - 1 else spare
+            self._res_block(blk, cur, t, y, H, W, mean_out=mean_out if j == n - 1 else None)
+            cur, spare = y, cur
+
+    # ---- search-facing entry points (hidden states stay in the pool)
+    def initial_to_pool(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor):
+        B = obs_nhwc.shape[0]
+        mean = self._buf("mean", (B, self.W), torch.float32)
+        self.represent(obs_nhwc, hidden_out, mean)
+        priors, value, _, _, _, _ = self._heads(mean, B, False, False)
+        return priors, value
+
+    def recurrent_in_pool(self, pool, in_slot, slot_stride, actions, hidden_out):
+        B = hidden_out.shape[0]
+        mean = self._buf("mean", (B, self.W), torch.float32)
+        self.dynamics(pool, in_slot, slot_stride, actions, hidden_out, mean)
+        priors, value, reward, _, _, _ = self._heads(mean, B, True, False)
+        return priors, value, reward
+
+    # ---- the reference's call surface (NCHW float32 in and out)
+    def _to_nhwc(self, x_nchw: torch.Tensor) -> torch.Tensor:
+        B, Cc, H, W = x_nchw.shape
+        x = x_nchw.contiguous().float()
+        y = torch.empty(B, H, W, Cc, dtype=torch.float32, device=self.device)
+        _lib.call("mz_nchw_to_nhwc_f32", _lib.ptr(x), _lib.ptr(y), B, Cc, H * W, _lib.current_stream())
+        return y if self.act_dtype == torch.float32 else y.to(self.act_dtype)
+
+    def _to_nchw(self, x_nhwc: torch.Tensor) -> torch.Tensor:
+        B, H, W, Cc = x_nhwc.shape
+        x = x_nhwc if x_nhwc.dtype == torch.float32 else x_nhwc.float()
+        y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=self.device)
+        _lib.call("mz_nhwc_to_nchw_f32", _lib.ptr(x.contiguous()), _lib.ptr(y), B, Cc, H * W, _lib.current_stream())
+        return y
+
+    def initial_inference(self, observation: torch.Tensor) -> NetworkOutput:
+        """model.py:332-338.  observation: float32 [B, C, H, W] on the device."""
+        obs = self._to_nhwc(observation.to(self.device))
+        B, H, W, _ = obs.shape
+        h, w = self.hidden_hw(H, W)
+        hidden = torch.empty(B, h, w, self.W, dtype=self.act_dtype, device=self.device)
+        mean = self._buf("mean", (B, self.W), torch.float32)
+        self.represent(obs, hidden, mean)
+        _, _, _, pl, vl, _ = self._heads(mean, B, False, True)
+        return NetworkOutput(vl, None, pl, self._to_nchw(hidden))
+
+    def recurrent_inference(self, hidden_state: torch.Tensor, action: torch.Tensor) -> NetworkOutput:
+        """model.py:340-348.  hidden_state float32 [B, C, h, w]; action integer [B, 1]."""
+        hs = self._to_nhwc(hidden_state.to(self.device))
+        B, h, w, _ = hs.shape
+        actions = action.to(self.device).view(B).to(torch.int32).contiguous()
+        out = torch.empty(B, h, w, self.W, dtype=self.act_dtype, device=self.device)
+        mean = self._buf("mean", (B, self.W), torch.float32)
+        self.dynamics(hs, None, 0, actions, out, mean)
+        _, _, _, pl, vl, rl = self._heads(mean, B, True, True)
+        return NetworkOutput(vl, rl, pl, self._to_nchw(out))

@@ -1,0 +1,65 @@
+"""Device frame stack and observation preparation (host wrappers of mz_ring_* /
+mz_prepare_observation).  Counterpart of CustomFrameStack (train.py:22-63) and
+prepare_observation (train.py:529-540) for B games at once."""
+import torch
+
+from . import _lib
+
+
+class FrameRing:
+    """Ring of the last ``depth`` uint8 frames of B games, resident on the device.
+
+    ``reset(frames)`` fills every slot with the given frame (train.py:49-50);
+    ``push(frames)`` replaces the oldest (train.py:59).  ``frames`` is a uint8
+    tensor [B, H, W, 3]; a pinned host tensor is copied asynchronously on the
+    current stream, so only 27 648 bytes per game cross PCIe per step."""
+
+    def __init__(self, B: int, depth: int = 32, H: int = 96, W: int = 96, device="cuda"):
+        self.B, self.depth, self.H, self.W = B, depth, H, W
+        self.device = torch.device(device)
+        self.frame_bytes = H * W * 3
+        if self.frame_bytes % 16:
+            raise ValueError("frame size must be a multiple of 16 bytes")
+        self.ring = torch.zeros(B, depth, H, W, 3, dtype=torch.uint8, device=self.device)
+        self.staging = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self.device)
+        self.newest = depth - 1
+
+    def _stage(self, frames: torch.Tensor) -> torch.Tensor:
+        assert frames.dtype == torch.uint8 and tuple(frames.shape) == (self.B, self.H, self.W, 3)
+        if frames.is_cuda:
+            return frames.contiguous()
+        self.staging.copy_(frames, non_blocking=True)
+        return self.staging
+
+    def reset(self, frames: torch.Tensor) -> None:
+        src = self._stage(frames)
+        self.newest = self.depth - 1
+        _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
+                  0, 1, _lib.current_stream())
+
+    def push(self, frames: torch.Tensor) -> None:
+        src = self._stage(frames)
+        self.newest = (self.newest + 1) % self.depth
+        _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
+                  self.newest, 0, _lib.current_stream())
+
+    def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None) -> torch.Tensor:
+        """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255."""
+        assert dtype in (torch.bfloat16, torch.float32)
+        if out is None:
+            out = torch.empty(self.B, self.H, self.W, 3 * self.depth, dtype=dtype, device=self.device)
+        _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
+                  self.B, self.depth, self.H * self.W, self.newest, _lib.current_stream())
+        return out
+
+
+def prepare_observation(observation: torch.Tensor) -> torch.Tensor:
+    """train.py:529-540 on the device: uint8 HWC or NHWC -> float32 CHW or NCHW, x / 255."""
+    single = observation.dim() == 3
+    x = observation.unsqueeze(0) if single else observation
+    assert x.dtype == torch.uint8
+    x = x.cuda().contiguous()
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    _lib.call("mz_prepare_observation", _lib.ptr(x), _lib.ptr(out), B, Cc, H * W, _lib.current_stream())
+    return out[0] if single else out
