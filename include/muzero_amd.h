@@ -138,6 +138,25 @@ int mz_conv3x3_f32(const float* in, const int32_t* in_slot, int32_t slot_stride,
                    const int32_t* actions, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                    int32_t stride, int32_t relu, mz_stream_t stream);
 
+/* bf16 MFMA 3x3 convolution, the throughput precision: same contract as
+ * mz_conv3x3_f32 with bf16 NHWC activations (in, residual, out), float32
+ * accumulation and bias, and weights pre-packed in MFMA fragment order:
+ *   wpk[((cc*9 + tap)*KC + kc)*NT + nt][lane][j] (bf16) =
+ *     w[cout = nt*16 + lane%16][cin = cc*chunk + kc*32 + 8*(lane/16) + j][tap]
+ * with KC = chunk/32, NT = Cout/16 and `chunk` from mz_conv3x3_bf16_info; the
+ * buffer must be followed by 2*NT*1024 readable bytes (prefetch overrun).
+ * mean_out (optional, float [B][Cout]): spatial mean of the output, only for
+ * shapes whose kernel holds a whole image (whole_image = 1).
+ * Kernels exist for the reference architecture's layer shapes (96x96x96->256 s2,
+ * 48x48x256->128 s2, 24x24x128->128, 24x24x128->256 s2, 12x12x256->256); any
+ * other shape returns MZ_E_ARG. */
+int mz_conv3x3_bf16_info(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride, int32_t* cin_chunk,
+                         int32_t* whole_image);
+int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk,
+                    const float* bias, const void* residual, void* out, const float* action_vec,
+                    const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                    int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream);
+
 /* x.mean(dim=(2,3)) (model.py:243, :275): float NHWC [B][HW][C] -> [B][C]. */
 int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
 

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "mz_tree_readout": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, _P]),
     "mz_select_action": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
     "mz_conv3x3_f32": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
+    "mz_conv3x3_bf16_info": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mz_conv3x3_bf16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_spatial_mean_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_heads": (C.c_int, [_P] + [C.c_int32] * 5 + [_P] * 10),
     "mz_support_to_scalar": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

@@ -1,0 +1,287 @@
+// bf16 MFMA 3x3 convolution (padding 1, stride 1 or 2) for gfx950, NHWC.
+//
+// Implicit GEMM with the operands arranged for CDNA4:
+//   * one workgroup (4 wavefronts) owns an output patch of TH x TW pixels of one
+//     image and ALL output channels; the input window of the patch (with its
+//     zero halo) is staged ONCE in LDS and then read 9 times, once per filter
+//     tap, as MFMA operand fragments (ds_read_b128, rows padded by 16 B so that
+//     the 16 pixels of a fragment fall on different bank groups);
+//   * the four wavefronts split the output channels, so weight fragments are
+//     private to a wavefront: they are pre-packed on the host in fragment order
+//     and stream straight from L2 into registers (1 KiB contiguous per
+//     wave-instruction), never through LDS;
+//   * v_mfma_f32_16x16x32_bf16 with the weights as the row operand: a lane ends
+//     up with 4 consecutive output channels of one pixel, so bias + residual +
+//     ReLU + bf16 packing and the 8-byte NHWC store need no cross-lane traffic.
+// Fused: folded-BatchNorm bias, residual add, ReLU, the dynamics network's
+// "hidden + conv1x1(one-hot action)" prologue, the gather of parent hidden
+// states from the node pool, and the spatial mean for the heads.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const __bf16* in;
+  const int* in_slot;
+  int slot_stride;
+  const __bf16* wpk;
+  const float* bias;
+  const __bf16* residual;
+  __bf16* out;
+  const float* avec;
+  const int* actions;
+  float* mean_out;
+  int relu;
+};
+
+template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, bool HALO_, int MINW_, int PF_ = 2>
+struct Cfg {
+  static constexpr int PF = PF_;  // weight prefetch distance in k-steps (1 or 2)
+  static constexpr int CIN = CIN_, CINC = CINC_, COUT = COUT_, S = S_, TH = TH_, TW = TW_, HIN = HIN_, WIN = WIN_;
+  static constexpr bool HALO = HALO_;
+  static constexpr int MINW = MINW_;
+  static constexpr int HO = (HIN - 1) / S + 1, WO = (WIN - 1) / S + 1;
+  static constexpr int PY = HO / TH, PX = WO / TW;
+  static constexpr int M = TH * TW, MT = (M + 15) / 16;
+  static constexpr int IH = HALO ? (TH - 1) * S + 3 : TH, IW = HALO ? (TW - 1) * S + 3 : TW;
+  static constexpr int ROWB = CINC * 2 + 16;
+  static constexpr int KC = CINC / 32, NCC = CIN / CINC;
+  static constexpr int NTILES = COUT / 16, WN = NTILES / 4;
+  static constexpr int ZROW = IH * IW;  // index of the all-zero row (no-halo variant)
+  static constexpr int LDS_BYTES = (IH * IW + (HALO ? 0 : 1)) * ROWB;
+  static constexpr int KSTEPS = NCC * 9 * KC;
+  static_assert(HO % TH == 0 && WO % TW == 0, "patches must tile the output");
+  static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % 64 == 0, "channel tiling");
+  static_assert(HALO || (S == 1 && TH == HIN && TW == WIN), "no-halo variant needs the whole image in LDS");
+};
+
+template <class C>
+__device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const float* av, int cc, int iy0, int ix0,
+                                            int tid) {
+  constexpr int UPP = C::CINC / 8;  // 16-byte units per pixel
+  constexpr int UNITS = C::IH * C::IW * UPP;
+#pragma unroll 4
+  for (int u = tid; u < UNITS; u += 256) {
+    const int pix = u / UPP, cu = u % UPP;
+    const int py = pix / C::IW, px = pix % C::IW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN) {
+      v = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
+      if (av) {
+        const float4 a0 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8 + 4);
+        v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
+        v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
+        v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
+        v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = v;
+  }
+  if constexpr (!C::HALO) {
+    if (tid <= UPP) {
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<bf16x8*>(lds + C::ZROW * C::ROWB + tid * 16) = z;
+    }
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(256, C::MINW) void conv3x3_bf16_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / (C::PY * C::PX), patch = blockIdx.x % (C::PY * C::PX);
+  const int oy0 = (patch / C::PX) * C::TH, ox0 = (patch % C::PX) * C::TW;
+  const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
+  const __bf16* src = a.in + img * (long)C::HIN * C::WIN * C::CIN;
+  const float* av = a.avec ? a.avec + (long)a.actions[b] * C::CIN : nullptr;
+  const int iy0 = C::HALO ? oy0 * C::S - 1 : 0, ix0 = C::HALO ? ox0 * C::S - 1 : 0;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[MT][WN];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight fragments: [k-step][n-tile][lane][8]; this wave's n-tiles are wave*WN .. +WN
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) + (long)wave * WN * 64 + lane;
+  constexpr int WSTEP = C::NTILES * 64;  // bf16x8 elements per k-step
+  bf16x8 w0[WN], w1[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    w0[nt] = wp[nt * 64];
+    if constexpr (C::PF == 2) w1[nt] = wp[WSTEP + nt * 64];
+  }
+  wp += C::PF * WSTEP;
+
+  for (int cc = 0; cc < C::NCC; ++cc) {
+    if (cc > 0) __syncthreads();
+    stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const int toff = C::HALO ? (dy * C::IW + dx) * C::ROWB : ((dy - 1) * C::IW + (dx - 1)) * C::ROWB;
+      // per-lane LDS byte address of this lane's pixel in each 16-pixel M tile, for this tap
+      // (recomputed per tap: 9 taps x MT cheap integer ops instead of 2*MT live registers)
+      int aaddr[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        int m = mt * 16 + r16;
+        if (m >= C::M) m = C::M - 1;  // padding rows recompute the last pixel; never stored
+        const int py = m / C::TW, px = m % C::TW;
+        aaddr[mt] = (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16 + toff;
+        if constexpr (!C::HALO) {
+          const bool ok = (unsigned)(py + dy - 1) < (unsigned)C::TH && (unsigned)(px + dx - 1) < (unsigned)C::TW;
+          if (!ok) aaddr[mt] = C::ZROW * C::ROWB + kq * 16;
+        }
+      }
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        bf16x8 w2[WN];
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];  // PF k-steps ahead (the buffer is padded)
+        wp += WSTEP;
+        bf16x8 af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt] + kc * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], af[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          if constexpr (C::PF == 2) {
+            w0[nt] = w1[nt];
+            w1[nt] = w2[nt];
+          } else {
+            w0[nt] = w2[nt];
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue: lane holds channels cbase..cbase+3 of pixel (mt*16 + r16)
+  float msum[WN][4];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int cbase = (wave * WN + nt) * 16 + kq * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
+    msum[nt][0] = msum[nt][1] = msum[nt][2] = msum[nt][3] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m < C::M) {
+        const int py = m / C::TW, px = m % C::TW;
+        const long o = (((long)b * C::HO + oy0 + py) * C::WO + ox0 + px) * C::COUT + cbase;
+        float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
+        float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
+        if (a.residual) {
+          const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.residual + o);
+          v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+        }
+        if (a.relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        msum[nt][0] += v0; msum[nt][1] += v1; msum[nt][2] += v2; msum[nt][3] += v3;
+        const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+        *reinterpret_cast<bf16x4*>(a.out + o) = ov;
+      }
+    }
+  }
+  if (a.mean_out) {  // host guarantees the patch is the whole image
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = msum[nt][r];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        msum[nt][r] = s;
+      }
+      if (r16 == 0) {
+        const int cbase = (wave * WN + nt) * 16 + kq * 4;
+        const float inv = 1.0f / (float)C::M;
+        *reinterpret_cast<float4*>(a.mean_out + (long)b * C::COUT + cbase) =
+            make_float4(msum[nt][0] * inv, msum[nt][1] * inv, msum[nt][2] * inv, msum[nt][3] * inv);
+      }
+    }
+  }
+}
+
+template <class C>
+int launch(const ConvArgs& a, int B, hipStream_t stream) {
+  static bool configured = false;
+  auto kern = conv3x3_bf16_kernel<C>;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv3x3_bf16: LDS attribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(256), C::LDS_BYTES, stream, a);
+  return mz::check_launch("mz_conv3x3_bf16");
+}
+
+// The reference architecture's five convolution shapes (model.py:178-215 with the
+// default config).           CIN CINC COUT S  TH  TW  HIN WIN halo  waves/SIMD
+using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, true, 2>;       // representation.conv1
+using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, true, 2>;    // downsample.0.conv
+using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, true, 2>;    // downsample.0.blocks
+using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, true, 2>;   // downsample.1.conv
+using ConvTrunk = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 1>; // every 256ch 12x12 layer
+
+template <class C>
+bool matches(int H, int W, int Cin, int Cout, int stride) {
+  return H == C::HIN && W == C::WIN && Cin == C::CIN && Cout == C::COUT && stride == C::S;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_conv3x3_bf16_info(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride, int32_t* cin_chunk,
+                         int32_t* whole_image) {
+  int cc = 0, whole = 0;
+  if (matches<ConvStem>(H, W, Cin, Cout, stride)) cc = ConvStem::CINC;
+  else if (matches<ConvDown0>(H, W, Cin, Cout, stride)) cc = ConvDown0::CINC;
+  else if (matches<ConvMid>(H, W, Cin, Cout, stride)) cc = ConvMid::CINC;
+  else if (matches<ConvDown1>(H, W, Cin, Cout, stride)) cc = ConvDown1::CINC;
+  else if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) { cc = ConvTrunk::CINC; whole = 1; }
+  else
+    return mz::fail(MZ_E_ARG, "conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
+                    Cout, stride);
+  if (cin_chunk) *cin_chunk = cc;
+  if (whole_image) *whole_image = whole;
+  return MZ_OK;
+}
+
+int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk,
+                    const float* bias, const void* residual, void* out, const float* action_vec,
+                    const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                    int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(in && wpk && bias && out && B > 0, "mz_conv3x3_bf16: null tensor or empty batch");
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv3x3_bf16: action_vec and actions go together");
+  ConvArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
+             static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
+  hipStream_t s = mz::as_stream(stream);
+  if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) return launch<ConvTrunk>(a, B, s);
+  MZ_REQUIRE(mean_out == nullptr, "mz_conv3x3_bf16: the fused spatial mean needs a whole-image kernel");
+  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch<ConvStem>(a, B, s);
+  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch<ConvDown0>(a, B, s);
+  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch<ConvMid>(a, B, s);
+  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<ConvDown1>(a, B, s);
+  return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
+                  Cout, stride);
+}
+
+}  // extern "C"

@@ -157,7 +157,8 @@ class _HeadWeights(C.Structure):
 
 # --------------------------------------------------------------------------- network
 class MuZeroNetwork:
-    def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0):
+    def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0,
+                 input_hw=(96, 96)):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         _lib.lib()  # fail now, loudly, if the HIP library is missing
@@ -170,6 +171,7 @@ class MuZeroNetwork:
         self.W = config.num_channels
         self.cin = config.observation_shape[0]
         self._buffers: Dict[tuple, torch.Tensor] = {}
+        self.input_hw = tuple(input_hw)
         self.load_state_dict(state_dict if state_dict is not None else init_state_dict(config, seed))
 
     # ---- parameters
@@ -197,8 +199,7 @@ class MuZeroNetwork:
         self.reward_head = Head(sd, "dynamics.reward_head", self.device)
         if not (self.policy.hidden == self.value_head.hidden == self.reward_head.hidden):
             raise NotImplementedError("the three heads must share one hidden width")
-        for layer in self.all_convs():
-            self._upload(layer)
+        self._upload_all()
 
     def state_dict(self):
         return self._state_dict
@@ -214,14 +215,26 @@ class MuZeroNetwork:
         for blk in self.dyn_blocks:
             yield from blk
 
-    def _upload(self, layer: ConvLayer) -> None:
-        layer.dev["bias"] = layer.b.contiguous().to(self.device)
-        if self.precision == "fp32":
-            # [Cout][Cin][ky][kx] -> [tap][Cin][Cout]
-            layer.dev["w"] = layer.w.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device)
-        else:
-            from . import mfma
-            layer.dev["w"] = mfma.pack_weights(layer.w).to(self.device)
+    def _upload_all(self) -> None:
+        """Device copies of the folded weights in the layout the kernels read."""
+        H, W = self.input_hw
+        shapes = []
+        for kind, item in self.rep_plan:
+            for layer in ([item] if kind == "conv" else item):
+                shapes.append((layer, H, W))
+                H, W = (H - 1) // layer.stride + 1, (W - 1) // layer.stride + 1
+        for layer in [self.dyn_first] + [l for blk in self.dyn_blocks for l in blk]:
+            shapes.append((layer, H, W))
+        for layer, h, w in shapes:
+            layer.dev["bias"] = layer.b.contiguous().to(self.device)
+            if self.precision == "fp32":
+                # [Cout][Cin][ky][kx] -> [tap][Cin][Cout]
+                layer.dev["w"] = layer.w.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device)
+            else:
+                from . import mfma
+                chunk, whole = mfma.kernel_info(h, w, layer.cin, layer.cout, layer.stride)
+                layer.whole_image = whole
+                layer.dev["w"] = mfma.pack_weights(layer.w, chunk).to(self.device)
 
     # ---- scratch
     def _buf(self, tag, shape, dtype=None):

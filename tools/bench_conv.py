@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time one bf16 MFMA convolution shape in isolation (HIP events on the launch stream)."""
+import argparse
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from muzero_amd import mfma
+
+SHAPES = {"stem": (96, 96, 256, 2), "down0": (48, 256, 128, 2), "mid": (24, 128, 128, 1),
+          "down1": (24, 128, 256, 2), "trunk": (12, 256, 256, 1)}
+
+
+class L:
+    pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="trunk")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+    H, cin, cout, stride = SHAPES[args.shape]
+    B = args.batch
+    layer = L()
+    layer.cin, layer.cout, layer.stride = cin, cout, stride
+    chunk, _ = mfma.kernel_info(H, H, cin, cout, stride)
+    w = torch.randn(cout, cin, 3, 3) / (3 * cin ** 0.5)
+    layer.dev = {"w": mfma.pack_weights(w, chunk).cuda(), "bias": torch.randn(cout).cuda()}
+    HO = (H - 1) // stride + 1
+    x = torch.randn(B, H, H, cin, device="cuda").to(torch.bfloat16)
+    res = torch.randn(B, HO, HO, cout, device="cuda").to(torch.bfloat16)
+    out = torch.empty(B, HO, HO, cout, dtype=torch.bfloat16, device="cuda")
+    for _ in range(5):
+        mfma.conv(layer, x, out, B, H, H, True, res, None, 0, None, None, None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        mfma.conv(layer, x, out, B, H, H, True, res, None, 0, None, None, None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.iters
+    flops = 2.0 * B * HO * HO * cout * cin * 9
+    print(f"{args.shape} B={B}: {ms * 1e3:.1f} us/launch, {flops / ms / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
