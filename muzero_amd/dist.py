@@ -1,0 +1,93 @@
+"""Multi-GPU layer: one process per GPU, games sharded across ranks, RCCL used
+only to broadcast network weights.
+
+Games are independent (own tree, own min/max statistics, own frame ring), so the
+search needs no collective: rank r of R owns games [r*B/R, (r+1)*B/R).  The one
+exchange on the path is the weight hand-over from the rank that holds fresh
+parameters to the others after a weight update - a single flat broadcast of the
+~62 MB float32 state (the counterpart of `self.network` being shared by every
+game in the reference's single process, train.py:155).
+"""
+import hashlib
+import os
+from collections import OrderedDict
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank); initialises torch.distributed when WORLD_SIZE > 1.
+    backend defaults to RCCL ("nccl") when a GPU is visible, else gloo."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) slice of `total` games for `rank`."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def state_checksum(sd) -> str:
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def broadcast_state_dict(sd, src: int = 0, device=None):
+    """Broadcast a state_dict from `src` as ONE flat float32 buffer (plus the integer
+    entries as a second small one).  Every rank must pass a state_dict with the same
+    keys and shapes (contents are ignored off-source).  Returns the received dict
+    (CPU tensors).  A no-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sd
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    fkeys = [k for k, v in sd.items() if v.is_floating_point()]
+    ikeys = [k for k, v in sd.items() if not v.is_floating_point()]
+    flat = torch.cat([sd[k].detach().reshape(-1).float() for k in fkeys]).to(device)
+    dist.broadcast(flat, src=src)
+    out = OrderedDict()
+    off = 0
+    flat = flat.cpu()
+    for k in sd:
+        if k in ikeys:
+            continue
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].view(sd[k].shape).to(sd[k].dtype).clone()
+        off += n
+    if ikeys:
+        iflat = torch.cat([sd[k].detach().reshape(-1).long() for k in ikeys]).to(device)
+        dist.broadcast(iflat, src=src)
+        iflat = iflat.cpu()
+        off = 0
+        for k in ikeys:
+            n = sd[k].numel()
+            out[k] = iflat[off:off + n].view(sd[k].shape).to(sd[k].dtype).clone()
+            off += n
+    return OrderedDict((k, out[k]) for k in sd)
+
+
+def verify_same_everywhere(sd) -> bool:
+    """True when every rank holds bit-identical parameters (checksum all-gather)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    digest = state_checksum(sd)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, digest)
+    return all(g == gathered[0] for g in gathered)

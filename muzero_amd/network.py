@@ -271,14 +271,21 @@ class MuZeroNetwork:
         self._conv(blk[1], tmp, out, H, W, relu=True, residual=x, mean_out=mean_out)
 
     def _heads(self, mean, B, with_reward: bool, want_logits: bool):
+        """Search mode (want_logits False) writes into persistent buffers, so a steady-state
+        search step allocates nothing; the reference-surface mode returns fresh tensors."""
         dev = self.device
         O = 2 * self.S + 1
-        priors = torch.empty(B, self.A, dtype=torch.float32, device=dev)
-        value = torch.empty(B, dtype=torch.float32, device=dev)
-        reward = torch.empty(B, dtype=torch.float32, device=dev) if with_reward else None
-        pl = torch.empty(B, self.A, dtype=torch.float32, device=dev) if want_logits else None
-        vl = torch.empty(B, O, dtype=torch.float32, device=dev) if want_logits else None
-        rl = torch.empty(B, O, dtype=torch.float32, device=dev) if (want_logits and with_reward) else None
+        if want_logits:
+            new = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            priors, value = new(B, self.A), new(B)
+            reward = new(B) if with_reward else None
+            pl, vl = new(B, self.A), new(B, O)
+            rl = new(B, O) if with_reward else None
+        else:
+            priors = self._buf("priors", (B, self.A), torch.float32)
+            value = self._buf("value", (B,), torch.float32)
+            reward = self._buf("reward", (B,), torch.float32) if with_reward else None
+            pl = vl = rl = None
         _lib.call("mz_heads", _lib.ptr(mean), B, self.W, self.policy.hidden, self.A, self.S,
                   C.byref(self.policy.c), C.byref(self.value_head.c),
                   C.byref(self.reward_head.c) if with_reward else None,

@@ -83,12 +83,10 @@ class BatchedMCTS:
         self.leaf_parent = self.trees.array("leaf_parent")
         self.leaf_action = self.trees.array("leaf_action")
 
-    def run(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None) -> SearchResult:
-        """observations: NHWC [B, H, W, C] in the network's activation dtype (e.g. from
-        FrameRing.observation).  noise: float64 [B, A] Dirichlet rows, or None for the
-        noise-free search of evaluate() (train.py:456-460)."""
+    def _search(self, observations: torch.Tensor, noise: Optional[torch.Tensor]) -> None:
         cfg = self.config
-        priors, _ = self.net.initial_to_pool(observations, self.pool[0])
+        priors, value = self.net.initial_to_pool(observations, self.pool[0])
+        self.root_priors, self.root_net_value = priors, value
         self.trees.root_init(priors, noise, cfg.root_exploration_fraction)
         for s in range(self.steps):
             self.trees.select()
@@ -96,7 +94,31 @@ class BatchedMCTS:
                                                                 self.leaf_action, self.pool[s + 1])
             self.trees.expand_backup(priors, value, reward, self.wave, cfg.discount)
         self.trees.readout(self.visits, self.root_values, self.probs)
+
+    def run(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None) -> SearchResult:
+        """observations: NHWC [B, H, W, C] in the network's activation dtype (e.g. from
+        FrameRing.observation).  noise: float64 [B, A] Dirichlet rows, or None for the
+        noise-free search of evaluate() (train.py:456-460).  The returned tensors are
+        reused by the next call."""
+        self._search(observations, noise)
         return SearchResult(self.visits, self.root_values, self.probs)
+
+    def capture(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """Record one whole search (initial inference, every simulation step, read-out)
+        into a HIP graph reading ``observations`` / ``noise`` in place.  Returns a
+        ``replay()`` callable: refill the two tensors, call it, read the result
+        tensors.  Worth it when B is small and the per-kernel launch cost shows."""
+        self._search(observations, noise)  # warm-up: sizes every scratch buffer
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._search(observations, noise)
+        result = SearchResult(self.visits, self.root_values, self.probs)
+
+        def replay() -> SearchResult:
+            graph.replay()
+            return result
+        return replay
 
 
 def policy_softmax(logits: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,78 @@
+"""Batched self-play step: the device counterpart of one iteration of the
+reference's self-play loop body (train.py:227-282) for B games at once.
+
+    frame -> FrameRing.push -> stacked observation -> BatchedMCTS.run
+          -> select_action for every game
+
+The environment itself stays on the host (the reference steps gymnasium / ALE
+there, train.py:279); ``SyntheticEnv`` stands in for it with random frames of the
+same shape so that the search path can be driven and timed without ALE.
+"""
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .prep import FrameRing
+from .search import BatchedMCTS, SearchResult
+from .tree import select_actions
+
+
+class SyntheticEnv:
+    """B environments producing uniform random 96x96x3 uint8 frames."""
+
+    def __init__(self, B: int, H: int = 96, W: int = 96, seed: int = 1234, device=None, pool: int = 4):
+        self.B, self.H, self.W = B, H, W
+        rng = np.random.default_rng(seed)
+        frames = rng.integers(0, 256, size=(pool, B, H, W, 3), dtype=np.uint8)
+        self.host = torch.from_numpy(frames)
+        if torch.cuda.is_available():
+            self.host = self.host.pin_memory()
+        self.dev = self.host.to(device) if device is not None else None
+        self.t = 0
+
+    def reset(self, on_device: bool = True) -> torch.Tensor:
+        self.t = 0
+        return (self.dev if on_device and self.dev is not None else self.host)[0]
+
+    def step(self, actions=None, on_device: bool = True) -> torch.Tensor:
+        self.t += 1
+        src = self.dev if on_device and self.dev is not None else self.host
+        return src[self.t % src.shape[0]]
+
+
+class SelfPlayWorker:
+    """Owns the frame ring, the search and the action choice for B games on one GPU."""
+
+    def __init__(self, config, network, batch_size: int, num_simulations: int = 50, wave: int = 1,
+                 frame_stack: int = 32, obs_hw=(96, 96), seed: int = 5678):
+        self.config = config
+        self.net = network
+        self.B = batch_size
+        self.A = config.action_space_size
+        self.ring = FrameRing(batch_size, frame_stack, obs_hw[0], obs_hw[1], network.device)
+        self.mcts = BatchedMCTS(config, network, batch_size, num_simulations, wave, obs_hw)
+        self.obs = torch.empty(batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack, dtype=network.act_dtype,
+                               device=network.device)
+        self.rng = np.random.default_rng(seed)
+        self.noise = torch.empty(batch_size, self.A, dtype=torch.float64, device=network.device)
+        self.u = torch.empty(batch_size, dtype=torch.float64, device=network.device)
+        self.sims = num_simulations
+
+    def reset(self, frames: torch.Tensor) -> None:
+        self.ring.reset(frames)
+
+    def draw_randomness(self) -> None:
+        """Dirichlet rows for the roots and uniforms for the action choice (host RNG)."""
+        alpha = getattr(self.config, "root_dirichlet_alpha", 0.3)
+        self.noise.copy_(torch.from_numpy(self.rng.dirichlet(np.full(self.A, alpha), size=self.B)), non_blocking=True)
+        self.u.copy_(torch.from_numpy(self.rng.random(self.B)), non_blocking=True)
+
+    def step(self, new_frames: Optional[torch.Tensor], temperature: float = 1.0, add_noise: bool = True):
+        """One move for all B games.  Returns (actions int32 [B] on the device, SearchResult)."""
+        if new_frames is not None:
+            self.ring.push(new_frames)
+        self.ring.observation(self.net.act_dtype, out=self.obs)
+        res: SearchResult = self.mcts.run(self.obs, self.noise if add_noise else None)
+        actions = select_actions(res.visit_counts, temperature, self.u if temperature != 0 else None)
+        return actions, res

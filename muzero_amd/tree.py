@@ -60,7 +60,7 @@ class DeviceTrees:
         assert priors.dtype == torch.float32 and priors.is_contiguous() and priors.shape == (self.B, self.A)
         if noise is not None:
             assert noise.dtype == torch.float64 and noise.is_contiguous() and noise.shape == (self.B, self.A)
-        keep = float(np.float32(1.0 - frac))
+        keep = float(np.float32(1.0 - frac))  # the float32 factor of prior * (1 - frac)
         _lib.call("mz_tree_root_init", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(priors),
                   _lib.ptr(noise), keep, float(frac), _lib.current_stream())
 
