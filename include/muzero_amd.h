@@ -161,12 +161,16 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
 int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
 
 /* One fully connected head with a single hidden layer (model.py:217-224,
- * :253-269): w1t float [C][Hd] and w2t float [Hd][O] are the TRANSPOSED
- * torch Linear weights. */
+ * :253-269), weights packed in float32 MFMA fragment order:
+ *   w1p[(t*(C/4) + ks)*64 + lane]  = W1[t*16 + lane%16][4*ks + lane/16]   (Hd/16 tiles)
+ *   w2p[(t*(Hd/4) + ks)*64 + lane] = W2[t*16 + lane%16][4*ks + lane/16]   (ceil(O/16) tiles,
+ *                                                       rows >= O are zero)
+ * with W1 [Hd][C], W2 [O][Hd] the torch Linear weights; b1 float [Hd];
+ * b2 float [ceil(O/16)*16] zero padded. */
 typedef struct mz_head_weights {
-  const float* w1t;
+  const float* w1p;
   const float* b1;
-  const float* w2t;
+  const float* w2p;
   const float* b2;
 } mz_head_weights;
 

@@ -57,6 +57,9 @@ def lib():
     """Load the library once; raise loudly if it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime: load it first so that this library binds to
+        # the same runtime instance (two runtimes in one process do not share devices)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MuZeroAmdError(
                 f"{LIB_PATH} not found: build it with `make -C muzero_amd/csrc` "

@@ -76,34 +76,25 @@ __global__ void spatial_mean_f32_kernel(const float* __restrict__ in, float* __r
 }
 
 // --------------------------------------------------------------------- heads
-// Policy / value / reward MLPs (one hidden layer each) on the spatial mean,
-// with the softmax over actions and the support decode fused
-// (model.py:243, :275-280, :397, :89-109).  One block handles HS samples so a
-// weight read from L2 is used HS times.
-constexpr int HS = 4;
+// Policy / value / reward MLPs (one hidden layer each) on the spatial mean, with
+// the softmax over actions and the support decode fused (model.py:243, :275-280,
+// :397, :89-109).  Exact float32 on the matrix cores: v_mfma_f32_16x16x4_f32 is
+// bit-for-bit a k-ordered fmaf chain.  One workgroup = 16 samples x one head; the
+// weights are the row operand, pre-packed on the host in fragment order
+// ([out tile][k/4][lane]: lane l holds W[tile*16 + l%16][4*kstep + l/16]) so that a
+// fragment is one coalesced 256-byte load; the 16 samples are the column operand,
+// read from LDS.  A lane ends up with 4 consecutive outputs of one sample.
 constexpr int kHeadsBlock = 256;
+constexpr int kHeadSamples = 16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HeadW {
-  const float* w1t;  // [C][Hd]   (transposed Linear weight)
+  const float* w1p;  // [Hd/16][C/4][64]
   const float* b1;   // [Hd]
-  const float* w2t;  // [Hd][O]
-  const float* b2;   // [O]
+  const float* w2p;  // [ceil(O/16)][Hd/4][64]
+  const float* b2;   // [ceil(O/16)*16]  (zero padded)
+  int out;           // O: number of outputs of this head
 };
-
-__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-  // red: kHeadsBlock/64 floats of LDS scratch
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const float o = __shfl_xor(v, m);
-    v = is_max ? fmaxf(v, o) : v + o;
-  }
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = red[0];
-  for (int i = 1; i < kHeadsBlock / 64; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
-  return r;
-}
 
 // softmax over the (up to 64) logits held one per lane of a wavefront
 __device__ __forceinline__ float wave_softmax(float lg, bool active) {
@@ -133,114 +124,114 @@ __device__ float inverse_value_transform(float x) {
   return sg * t;
 }
 
-// hidden layer for one head: hid[s][j] = relu(b1[j] + sum_k mean[s][k] * w1t[k][j])
-__device__ void head_hidden(const HeadW& hw, const float* mean_s, float* hid_s, int C, int Hd, int ns) {
-  for (int j = threadIdx.x; j < Hd; j += kHeadsBlock) {
-    float a[HS];
-#pragma unroll
-    for (int s = 0; s < HS; ++s) a[s] = hw.b1[j];
-    for (int k = 0; k < C; ++k) {
-      const float wv = hw.w1t[(long)k * Hd + j];
-#pragma unroll
-      for (int s = 0; s < HS; ++s) a[s] = fmaf(mean_s[s * C + k], wv, a[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < HS; ++s) hid_s[s * Hd + j] = fmaxf(a[s], 0.f);
-  }
-}
-
-// output layer into LDS logits[s][o]
-__device__ void head_out(const HeadW& hw, const float* hid_s, float* logit_s, int Hd, int O, int ldo) {
-  for (int o = threadIdx.x; o < O; o += kHeadsBlock) {
-    float a[HS];
-#pragma unroll
-    for (int s = 0; s < HS; ++s) a[s] = hw.b2[o];
-    for (int k = 0; k < Hd; ++k) {
-      const float wv = hw.w2t[(long)k * O + o];
-#pragma unroll
-      for (int s = 0; s < HS; ++s) a[s] = fmaf(hid_s[s * Hd + k], wv, a[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < HS; ++s) logit_s[s * ldo + o] = a[s];
-  }
-}
-
-// softmax expectation over bins -S..S of logits[0..O), then the inverse transform
-__device__ float decode_support(const float* lg, int O, float* red) {
-  const int S = O / 2;
+// softmax expectation over bins -S..S of lg[0..O) by ONE wavefront, then the inverse transform
+__device__ float wave_decode_support(const float* lg, int O) {
+  const int lane = threadIdx.x & 63, S = O / 2;
   float m = -__builtin_inff();
-  for (int o = threadIdx.x; o < O; o += kHeadsBlock) m = fmaxf(m, lg[o]);
-  m = block_reduce(m, red, true);
+  for (int o = lane; o < O; o += 64) m = fmaxf(m, lg[o]);
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
   float den = 0.f, num = 0.f;
-  for (int o = threadIdx.x; o < O; o += kHeadsBlock) {
+  for (int o = lane; o < O; o += 64) {
     const float e = expf(lg[o] - m);
     den += e;
     num += e * (float)(o - S);
   }
-  den = block_reduce(den, red, false);
-  num = block_reduce(num, red, false);
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    den += __shfl_xor(den, k);
+    num += __shfl_xor(num, k);
+  }
   return inverse_value_transform(num / den);
 }
 
-__global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
-    const float* __restrict__ mean, int B, int C, int Hd, int A, int O, HeadW pol, HeadW val, HeadW rew,
-    int with_reward, float* __restrict__ priors, float* __restrict__ value, float* __restrict__ reward,
-    float* __restrict__ policy_logits, float* __restrict__ value_logits, float* __restrict__ reward_logits) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* mean_s = reinterpret_cast<float*>(smem);  // [HS][C]
-  float* hid_s = mean_s + HS * C;                  // [HS][Hd]
-  float* logit_s = hid_s + HS * Hd;                // [HS][ldo]
-  float* red = logit_s + HS * (O > A ? O : A);     // [4]
-  const int ldo = O > A ? O : A;
-  const int b0 = blockIdx.x * HS;
-  const int ns = B - b0 < HS ? B - b0 : HS;
-  for (int i = threadIdx.x; i < HS * C; i += kHeadsBlock) {
-    const int s = i / C;
-    mean_s[i] = s < ns ? mean[(long)(b0 + s) * C + (i % C)] : 0.f;
-  }
-  __syncthreads();
-
-  // ---- policy: logits -> softmax priors
-  head_hidden(pol, mean_s, hid_s, C, Hd, ns);
-  __syncthreads();
-  head_out(pol, hid_s, logit_s, Hd, A, ldo);
-  __syncthreads();
-  if (threadIdx.x < HS * 64) {  // one wavefront per sample, A <= 64
-    const int s = threadIdx.x >> 6, a = threadIdx.x & 63;
-    const float lg = a < A ? logit_s[s * ldo + a] : -__builtin_inff();
-    const float pr = wave_softmax(lg, a < A);
-    if (s < ns && a < A) {
-      priors[(long)(b0 + s) * A + a] = pr;
-      if (policy_logits) policy_logits[(long)(b0 + s) * A + a] = lg;
+// one dense layer for 16 samples: dst[s][o] = act(bias[o] + sum_k src[s][k] * W[o][k]);
+// out tiles are dealt round-robin to the 4 wavefronts, 4 tiles in flight per wavefront
+__device__ __forceinline__ void dense16(const float* __restrict__ wp, const float* __restrict__ bias,
+                                        const float* src, int lds, float* dst, int ldd, int K, int tiles,
+                                        bool relu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ks_n = K / 4;
+  const float* sp = src + (lane & 15) * lds + (lane >> 4);
+  for (int t0 = wave; t0 < tiles; t0 += 16) {
+    f32x4 acc[4];
+    const float* w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int t = t0 + 4 * i < tiles ? t0 + 4 * i : t0;  // idle slots recompute tile t0
+      w[i] = wp + (long)t * ks_n * 64 + lane;
     }
-  }
-  __syncthreads();
-
-  // ---- value and (optionally) reward: logits -> decoded scalar
-  for (int h = 0; h < (with_reward ? 2 : 1); ++h) {
-    const HeadW& hw = h == 0 ? val : rew;
-    float* dst = h == 0 ? value : reward;
-    float* lg_out = h == 0 ? value_logits : reward_logits;
-    head_hidden(hw, mean_s, hid_s, C, Hd, ns);
-    __syncthreads();
-    head_out(hw, hid_s, logit_s, Hd, O, ldo);
-    __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-      const float y = decode_support(logit_s + s * ldo, O, red);
-      if (threadIdx.x == 0) dst[b0 + s] = y;
-      if (lg_out)
-        for (int o = threadIdx.x; o < O; o += kHeadsBlock) lg_out[(long)(b0 + s) * O + o] = logit_s[s * ldo + o];
+    for (int ks = 0; ks < ks_n; ++ks) {
+      const float bfrag = sp[ks * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][(long)ks * 64], bfrag, acc[i], 0, 0, 0);
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + 4 * i;
+      if (t < tiles) {
+        const int o = t * 16 + (lane >> 4) * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + o);
+        float v0 = acc[i][0] + bv.x, v1 = acc[i][1] + bv.y, v2 = acc[i][2] + bv.z, v3 = acc[i][3] + bv.w;
+        if (relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        float* d = dst + (lane & 15) * ldd + o;
+        d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+      }
+    }
   }
 }
 
-// decode only: logits [n][O] -> scalar [n]  (support_to_scalar, model.py:98-109)
-__global__ __launch_bounds__(kHeadsBlock) void decode_kernel(const float* __restrict__ logits, int O,
+__global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
+    const float* __restrict__ mean, int B, int C, int Hd, int A, HeadW pol, HeadW val, HeadW rew,
+    float* __restrict__ priors, float* __restrict__ value, float* __restrict__ reward,
+    float* __restrict__ policy_logits, float* __restrict__ value_logits, float* __restrict__ reward_logits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int head = blockIdx.y;  // 0 policy, 1 value, 2 reward
+  const HeadW hw = head == 0 ? pol : (head == 1 ? val : rew);
+  const int O = hw.out, otiles = (O + 15) / 16;
+  const int ldm = C + 1, ldh = Hd + 1, ldo = otiles * 16 + 1;
+  float* hid_s = reinterpret_cast<float*>(smem);  // [16][Hd+1]
+  float* mean_s = hid_s + kHeadSamples * ldh;     // [16][C+1]
+  float* logit_s = mean_s;                        // [16][otiles*16+1], reuses the mean once it is consumed
+  const int b0 = blockIdx.x * kHeadSamples;
+  const int ns = B - b0 < kHeadSamples ? B - b0 : kHeadSamples;
+  for (int i = threadIdx.x; i < kHeadSamples * C; i += kHeadsBlock) {
+    const int s = i / C, k = i % C;
+    mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
+  }
+  __syncthreads();
+  dense16(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  __syncthreads();
+  dense16(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* lg_out = head == 0 ? policy_logits : (head == 1 ? value_logits : reward_logits);
+  for (int s = wave; s < ns; s += kHeadsBlock / 64) {  // one wavefront per sample
+    const float* lg = logit_s + s * ldo;
+    if (head == 0) {
+      const float pr = wave_softmax(lane < A ? lg[lane] : 0.f, lane < A);
+      if (lane < A) priors[(long)(b0 + s) * A + lane] = pr;
+    } else {
+      const float y = wave_decode_support(lg, O);
+      if (lane == 0) (head == 1 ? value : reward)[b0 + s] = y;
+    }
+    if (lg_out)
+      for (int o = lane; o < O; o += 64) lg_out[(long)(b0 + s) * O + o] = lg[o];
+  }
+}
+
+// decode only: logits [n][O] -> scalar [n]  (support_to_scalar, model.py:98-109), one wavefront per row
+__global__ __launch_bounds__(kHeadsBlock) void decode_kernel(const float* __restrict__ logits, int n, int O,
                                                              float* __restrict__ out) {
-  __shared__ float red[kHeadsBlock / 64];
-  const float y = decode_support(logits + (long)blockIdx.x * O, O, red);
-  if (threadIdx.x == 0) out[blockIdx.x] = y;
+  const int row = blockIdx.x * (kHeadsBlock / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float y = wave_decode_support(logits + (long)row * O, O);
+  if ((threadIdx.x & 63) == 0) out[row] = y;
 }
 
 // softmax(policy_logits, dim=1) (model.py:397): one wavefront per row
@@ -322,25 +313,28 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
              float* reward_logits, mz_stream_t stream) {
   MZ_REQUIRE(mean && policy && value_w && priors && value, "mz_heads: null argument");
   MZ_REQUIRE((reward_w == nullptr) == (reward == nullptr), "mz_heads: reward weights and output go together");
-  MZ_REQUIRE(B > 0 && C > 0 && Hd > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && S >= 1, "mz_heads: bad sizes");
+  MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && S >= 1, "mz_heads: bad sizes");
+  MZ_REQUIRE(C > 0 && C % 4 == 0 && Hd > 0 && Hd % 16 == 0, "mz_heads: C must be a multiple of 4 and Hd of 16");
   const int O = 2 * S + 1;
-  const int ldo = O > A ? O : A;
-  const size_t lds = (size_t)(HS * C + HS * Hd + HS * ldo + kHeadsBlock / 64) * sizeof(float);
+  const int omax = ((O > A ? O : A) + 15) / 16 * 16;
+  const size_t lds = (size_t)kHeadSamples * ((Hd + 1) + (C > omax ? C + 1 : omax + 1)) * sizeof(float);
   MZ_REQUIRE(lds <= 64 * 1024, "mz_heads: layer sizes exceed the LDS budget");
-  auto cvt = [](const mz_head_weights* h) {
-    HeadW r{nullptr, nullptr, nullptr, nullptr};
-    if (h) r = HeadW{h->w1t, h->b1, h->w2t, h->b2};
+  auto cvt = [](const mz_head_weights* h, int out) {
+    HeadW r{nullptr, nullptr, nullptr, nullptr, out};
+    if (h) r = HeadW{h->w1p, h->b1, h->w2p, h->b2, out};
     return r;
   };
-  hipLaunchKernelGGL(heads_kernel, dim3((B + HS - 1) / HS), dim3(kHeadsBlock), lds, mz::as_stream(stream), mean,
-                     B, C, Hd, A, O, cvt(policy), cvt(value_w), cvt(reward_w), reward_w ? 1 : 0, priors, value,
-                     reward, policy_logits, value_logits, reward_logits);
+  hipLaunchKernelGGL(heads_kernel, dim3((B + kHeadSamples - 1) / kHeadSamples, reward_w ? 3 : 2),
+                     dim3(kHeadsBlock), lds, mz::as_stream(stream), mean, B, C, Hd, A, cvt(policy, A),
+                     cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits, value_logits,
+                     reward_logits);
   return mz::check_launch("mz_heads");
 }
 
 int mz_support_to_scalar(const float* logits, int32_t n, int32_t S, float* out, mz_stream_t stream) {
   MZ_REQUIRE(logits && out && n > 0 && S >= 1, "mz_support_to_scalar: bad arguments");
-  hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(kHeadsBlock), 0, mz::as_stream(stream), logits, 2 * S + 1, out);
+  hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(kHeadsBlock), 0, mz::as_stream(stream), logits, n,
+                     2 * S + 1, out);
   return mz::check_launch("mz_support_to_scalar");
 }
 

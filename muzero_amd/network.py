@@ -136,23 +136,37 @@ class ConvLayer:
         self.dev: Dict[str, torch.Tensor] = {}
 
 
+def _pack_linear(w: torch.Tensor) -> torch.Tensor:
+    """torch Linear weight [O][K] -> float32 MFMA fragments [ceil(O/16)][K/4][lane = kq*16 + r]
+    holding W[tile*16 + r][4*kstep + kq]; rows beyond O are zero."""
+    O, K = w.shape
+    tiles = (O + 15) // 16
+    wp = torch.zeros(tiles * 16, K, dtype=torch.float32)
+    wp[:O] = w.float()
+    return wp.view(tiles, 16, K // 4, 4).permute(0, 2, 3, 1).contiguous().view(-1)
+
+
 class Head:
     def __init__(self, sd, name: str, device):
         keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
         if len(keys) != 2:
             raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
         k1, k2 = keys
-        self.w1t = sd[f"{name}.{k1}.weight"].float().t().contiguous().to(device)
+        w1, w2 = sd[f"{name}.{k1}.weight"], sd[f"{name}.{k2}.weight"]
+        self.hidden, self.out = w1.shape[0], w2.shape[0]
+        if self.hidden % 16 or w1.shape[1] % 4:
+            raise NotImplementedError(f"{name}: hidden width must be a multiple of 16 and the input of 4")
+        self.w1p = _pack_linear(w1).to(device)
         self.b1 = sd[f"{name}.{k1}.bias"].float().contiguous().to(device)
-        self.w2t = sd[f"{name}.{k2}.weight"].float().t().contiguous().to(device)
-        self.b2 = sd[f"{name}.{k2}.bias"].float().contiguous().to(device)
-        self.hidden = self.w1t.shape[1]
-        self.out = self.w2t.shape[1]
-        self.c = _HeadWeights(self.w1t.data_ptr(), self.b1.data_ptr(), self.w2t.data_ptr(), self.b2.data_ptr())
+        self.w2p = _pack_linear(w2).to(device)
+        b2 = torch.zeros((self.out + 15) // 16 * 16)
+        b2[:self.out] = sd[f"{name}.{k2}.bias"].float()
+        self.b2 = b2.to(device)
+        self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr())
 
 
 class _HeadWeights(C.Structure):
-    _fields_ = [("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2t", C.c_void_p), ("b2", C.c_void_p)]
+    _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p)]
 
 
 # --------------------------------------------------------------------------- network
@@ -270,7 +284,7 @@ class MuZeroNetwork:
         self._conv(blk[0], x, tmp, H, W, relu=True)
         self._conv(blk[1], tmp, out, H, W, relu=True, residual=x, mean_out=mean_out)
 
-    def _heads(self, mean, B, with_reward: bool, want_logits: bool):
+    def _heads(self, mean, B, with_reward: bool, want_logits: bool, tag: str = ""):
         """Search mode (want_logits False) writes into persistent buffers, so a steady-state
         search step allocates nothing; the reference-surface mode returns fresh tensors."""
         dev = self.device
@@ -282,8 +296,8 @@ class MuZeroNetwork:
             pl, vl = new(B, self.A), new(B, O)
             rl = new(B, O) if with_reward else None
         else:
-            priors = self._buf("priors", (B, self.A), torch.float32)
-            value = self._buf("value", (B,), torch.float32)
+            priors = self._buf("priors" + tag, (B, self.A), torch.float32)
+            value = self._buf("value" + tag, (B,), torch.float32)
             reward = self._buf("reward", (B,), torch.float32) if with_reward else None
             pl = vl = rl = None
         _lib.call("mz_heads", _lib.ptr(mean), B, self.W, self.policy.hidden, self.A, self.S,
@@ -339,8 +353,8 @@ class MuZeroNetwork:
         B = obs_nhwc.shape[0]
         mean = self._buf("mean", (B, self.W), torch.float32)
         self.represent(obs_nhwc, hidden_out, mean)
-        priors, value, _, _, _, _ = self._heads(mean, B, False, False)
-        return priors, value
+        priors, value, _, _, _, _ = self._heads(mean, B, False, False, tag="_root")  # own buffers: they
+        return priors, value                                # outlive the recurrent steps that follow
 
     def recurrent_in_pool(self, pool, in_slot, slot_stride, actions, hidden_out):
         B = hidden_out.shape[0]
