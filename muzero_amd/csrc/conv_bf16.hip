@@ -16,6 +16,8 @@
 // Fused: folded-BatchNorm bias, residual add, ReLU, the dynamics network's
 // "hidden + conv1x1(one-hot action)" prologue, the gather of parent hidden
 // states from the node pool, and the spatial mean for the heads.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -38,8 +40,11 @@ struct ConvArgs {
   int relu;
 };
 
-template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, bool HALO_, int MINW_, int PF_ = 2>
+template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, bool HALO_, int MINW_, int PF_ = 2,
+          int NW_ = 4>
 struct Cfg {
+  static constexpr int NW = NW_;          // wavefronts per workgroup; they split the output channels
+  static constexpr int THREADS = 64 * NW_;
   static constexpr int PF = PF_;  // weight prefetch distance in k-steps (1 or 2)
   static constexpr int CIN = CIN_, CINC = CINC_, COUT = COUT_, S = S_, TH = TH_, TW = TW_, HIN = HIN_, WIN = WIN_;
   static constexpr bool HALO = HALO_;
@@ -50,12 +55,12 @@ struct Cfg {
   static constexpr int IH = HALO ? (TH - 1) * S + 3 : TH, IW = HALO ? (TW - 1) * S + 3 : TW;
   static constexpr int ROWB = CINC * 2 + 16;
   static constexpr int KC = CINC / 32, NCC = CIN / CINC;
-  static constexpr int NTILES = COUT / 16, WN = NTILES / 4;
+  static constexpr int NTILES = COUT / 16, WN = NTILES / NW;
   static constexpr int ZROW = IH * IW;  // index of the all-zero row (no-halo variant)
   static constexpr int LDS_BYTES = (IH * IW + (HALO ? 0 : 1)) * ROWB;
   static constexpr int KSTEPS = NCC * 9 * KC;
   static_assert(HO % TH == 0 && WO % TW == 0, "patches must tile the output");
-  static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % 64 == 0, "channel tiling");
+  static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % (16 * NW) == 0, "channel tiling");
   static_assert(HALO || (S == 1 && TH == HIN && TW == WIN), "no-halo variant needs the whole image in LDS");
 };
 
@@ -65,7 +70,7 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
   constexpr int UPP = C::CINC / 8;  // 16-byte units per pixel
   constexpr int UNITS = C::IH * C::IW * UPP;
 #pragma unroll 4
-  for (int u = tid; u < UNITS; u += 256) {
+  for (int u = tid; u < UNITS; u += C::THREADS) {
     const int pix = u / UPP, cu = u % UPP;
     const int py = pix / C::IW, px = pix % C::IW;
     const int iy = iy0 + py, ix = ix0 + px;
@@ -92,7 +97,7 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
 }
 
 template <class C>
-__global__ __launch_bounds__(256, C::MINW) void conv3x3_bf16_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -228,7 +233,7 @@ int launch(const ConvArgs& a, int B, hipStream_t stream) {
     if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv3x3_bf16: LDS attribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(256), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), C::LDS_BYTES, stream, a);
   return mz::check_launch("mz_conv3x3_bf16");
 }
 
@@ -238,7 +243,11 @@ using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, true, 2>;       // representa
 using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, true, 2>;    // downsample.0.conv
 using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, true, 2>;    // downsample.0.blocks
 using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, true, 2>;   // downsample.1.conv
-using ConvTrunk = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 1>; // every 256ch 12x12 layer
+using ConvTrunk = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 1>;
+// experimental trunk variants (selected with MZ_TRUNK_VARIANT)
+using ConvTrunkV1 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 4, 2, 8>;  // 8 waves, <=128 regs, 2 WG/CU
+using ConvTrunkV2 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 2, 8>;  // 8 waves, <=256 regs, 1 WG/CU
+using ConvTrunkV3 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, true, 1, 2, 4>;   // 4 waves, halo, 512 regs, 1 WG/CU // every 256ch 12x12 layer
 
 template <class C>
 bool matches(int H, int W, int Cin, int Cout, int stride) {
@@ -274,7 +283,13 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   ConvArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
   hipStream_t s = mz::as_stream(stream);
-  if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) return launch<ConvTrunk>(a, B, s);
+  if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) {
+    static const int variant = getenv("MZ_TRUNK_VARIANT") ? atoi(getenv("MZ_TRUNK_VARIANT")) : 0;
+    if (variant == 1) return launch<ConvTrunkV1>(a, B, s);
+    if (variant == 2) return launch<ConvTrunkV2>(a, B, s);
+    if (variant == 3) return launch<ConvTrunkV3>(a, B, s);
+    return launch<ConvTrunk>(a, B, s);
+  }
   MZ_REQUIRE(mean_out == nullptr, "mz_conv3x3_bf16: the fused spatial mean needs a whole-image kernel");
   if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch<ConvStem>(a, B, s);
   if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch<ConvDown0>(a, B, s);

@@ -84,7 +84,7 @@ __global__ void spatial_mean_f32_kernel(const float* __restrict__ in, float* __r
 // ([out tile][k/4][lane]: lane l holds W[tile*16 + l%16][4*kstep + l/16]) so that a
 // fragment is one coalesced 256-byte load; the 16 samples are the column operand,
 // read from LDS.  A lane ends up with 4 consecutive outputs of one sample.
-constexpr int kHeadsBlock = 256;
+constexpr int kHeadsBlock = 1024;
 constexpr int kHeadSamples = 16;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -146,32 +146,53 @@ __device__ float wave_decode_support(const float* lg, int O) {
 }
 
 // one dense layer for 16 samples: dst[s][o] = act(bias[o] + sum_k src[s][k] * W[o][k]);
-// out tiles are dealt round-robin to the 4 wavefronts, 4 tiles in flight per wavefront
+// out tiles are dealt round-robin to the wavefronts, up to 4 tiles in flight per wavefront;
+// U k-steps of weight fragments are loaded ahead of their MFMAs to cover the L2 latency
+template <int U>
 __device__ __forceinline__ void dense16(const float* __restrict__ wp, const float* __restrict__ bias,
                                         const float* src, int lds, float* dst, int ldd, int K, int tiles,
                                         bool relu) {
+  constexpr int NW = kHeadsBlock / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ks_n = K / 4;
   const float* sp = src + (lane & 15) * lds + (lane >> 4);
-  for (int t0 = wave; t0 < tiles; t0 += 16) {
+  for (int t0 = wave; t0 < tiles; t0 += 4 * NW) {
     f32x4 acc[4];
     const float* w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int t = t0 + 4 * i < tiles ? t0 + 4 * i : t0;  // idle slots recompute tile t0
+      const int t = t0 + NW * i < tiles ? t0 + NW * i : t0;  // idle slots recompute tile t0
       w[i] = wp + (long)t * ks_n * 64 + lane;
     }
-    for (int ks = 0; ks < ks_n; ++ks) {
-      const float bfrag = sp[ks * 4];
+    const bool multi = t0 + NW < tiles;  // wave-uniform: more than one live tile
+    for (int ks = 0; ks < ks_n; ks += U) {
+      float wf[4][U], bf[U];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i][(long)ks * 64], bfrag, acc[i], 0, 0, 0);
+      for (int u = 0; u < U; ++u) {
+        bf[u] = sp[(ks + u) * 4];
+        wf[0][u] = w[0][(long)(ks + u) * 64];
+      }
+      if (multi) {
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+          for (int u = 0; u < U; ++u) wf[i][u] = w[i][(long)(ks + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0][u], bf[u], acc[0], 0, 0, 0);
+        if (multi) {
+#pragma unroll
+          for (int i = 1; i < 4; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][u], bf[u], acc[i], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int t = t0 + 4 * i;
-      if (t < tiles) {
+      const int t = t0 + NW * i;
+      if (t < tiles && (i == 0 || multi)) {
         const int o = t * 16 + (lane >> 4) * 4;
         const float4 bv = *reinterpret_cast<const float4*>(bias + o);
         float v0 = acc[i][0] + bv.x, v1 = acc[i][1] + bv.y, v2 = acc[i][2] + bv.z, v3 = acc[i][3] + bv.w;
@@ -183,6 +204,12 @@ __device__ __forceinline__ void dense16(const float* __restrict__ wp, const floa
       }
     }
   }
+}
+
+__device__ __forceinline__ void dense16_any(const float* wp, const float* bias, const float* src, int lds,
+                                            float* dst, int ldd, int K, int tiles, bool relu) {
+  if (K % 32 == 0) dense16<8>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
+  else dense16<1>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
 }
 
 __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
@@ -204,9 +231,9 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
   }
   __syncthreads();
-  dense16(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   __syncthreads();
-  dense16(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  dense16_any(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -226,9 +253,9 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
 }
 
 // decode only: logits [n][O] -> scalar [n]  (support_to_scalar, model.py:98-109), one wavefront per row
-__global__ __launch_bounds__(kHeadsBlock) void decode_kernel(const float* __restrict__ logits, int n, int O,
-                                                             float* __restrict__ out) {
-  const int row = blockIdx.x * (kHeadsBlock / 64) + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ logits, int n, int O,
+                                                     float* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   const float y = wave_decode_support(logits + (long)row * O, O);
   if ((threadIdx.x & 63) == 0) out[row] = y;
@@ -333,7 +360,7 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
 
 int mz_support_to_scalar(const float* logits, int32_t n, int32_t S, float* out, mz_stream_t stream) {
   MZ_REQUIRE(logits && out && n > 0 && S >= 1, "mz_support_to_scalar: bad arguments");
-  hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(kHeadsBlock), 0, mz::as_stream(stream), logits, n,
+  hipLaunchKernelGGL(decode_kernel, dim3((n + 3) / 4), dim3(256), 0, mz::as_stream(stream), logits, n,
                      2 * S + 1, out);
   return mz::check_launch("mz_support_to_scalar");
 }
