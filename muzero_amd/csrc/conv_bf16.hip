@@ -20,6 +20,12 @@
 
 #include "common.h"
 
+namespace mz {
+int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                    const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream);
+}
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -285,6 +291,9 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   hipStream_t s = mz::as_stream(stream);
   if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) {
     static const int variant = getenv("MZ_TRUNK_VARIANT") ? atoi(getenv("MZ_TRUNK_VARIANT")) : 0;
+    if (variant == 4)
+      return mz::conv_trunk_bf16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out,
+                                 B, relu, s);
     if (variant == 1) return launch<ConvTrunkV1>(a, B, s);
     if (variant == 2) return launch<ConvTrunkV2>(a, B, s);
     if (variant == 3) return launch<ConvTrunkV3>(a, B, s);

@@ -1,0 +1,263 @@
+// The hot kernel of the search: 3x3 convolution 256 -> 256 channels on 12x12
+// images (every layer of the dynamics network and 18 of the 25 representation
+// layers; model.py:146-148, :213), bf16 in / fp32 accumulate on the matrix cores.
+//
+// One workgroup = one image; its 8 wavefronts split the 256 output channels
+// (32 each), so a wavefront's weight fragments are private and stream from L2
+// straight into registers in host-packed fragment order.  The image lives in LDS
+// for all 9 taps in a PLANAR layout [16-byte channel chunk][pixel]: the 16 pixels
+// of an MFMA operand fragment are then 16 consecutive 16-byte slots for every
+// tap shift, which makes each ds_read_b128 lane group conflict-free (a
+// pixel-major layout, padded or not, always puts two lanes of a group on one
+// bank group because half of the group reads the next channel chunk).  Pixels
+// 144..159 of every plane are zero: lanes whose tap falls outside the image read
+// pixel 144 instead of being masked.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kPix = 144, kSide = 12, kCh = 256;
+constexpr int kPixPad = 160;                 // pixels per plane incl. the zero pixels
+constexpr int kPlaneB = kPixPad * 16;        // bytes per channel-chunk plane
+constexpr int kPlanes = kCh / 8;             // 32 planes of 8 channels
+constexpr int kLdsBytes = kPlanes * kPlaneB; // 81 920
+constexpr int kMT = kPix / 16;               // 9 pixel tiles
+constexpr int kKC = kCh / 32;                // 8 k-steps per tap
+
+struct TrunkArgs {
+  const __bf16* in;
+  const int* in_slot;
+  int slot_stride;
+  const __bf16* wpk;
+  const float* bias;
+  const __bf16* residual;
+  __bf16* out;
+  const float* avec;
+  const int* actions;
+  float* mean_out;
+  int relu;
+};
+
+template <int NW>
+__device__ __forceinline__ void stage_image(char* lds, const __bf16* src, const float* av, int wave, int lane) {
+  // 72 blocks of (16 pixels x 4 channel chunks); lane = chunk*16 + pixel: global reads are
+  // 64-byte runs per pixel, LDS writes are 16 consecutive slots per 16 lanes
+  const int pl = lane & 15, qq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 72 / NW; ++j) {
+    const int it = wave + NW * j;
+    const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
+    if (av) {
+      const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+      v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
+      v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
+      v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
+      v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+    }
+    *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v;
+  }
+  // zero pixels 144..159 of every plane: 32 planes x 16 slots = 512 slots
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = wave * 64 + lane; s < kPlanes * 16; s += NW * 64)
+    *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
+}
+
+// LDS region B: the residual image on the way in, the output image on the way out,
+// pixel-major [pixel][256 ch] bf16 with 16 bytes of row padding
+constexpr int kRowB = kCh * 2 + 16;
+constexpr int kOutBytes = kPix * kRowB;           // 76 032
+constexpr int kLdsTotal = kLdsBytes + kOutBytes;  // 157 952 of the CU's 163 840
+
+template <int NW, int PF, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* ldsB = lds + kLdsBytes;
+  constexpr int WN = 16 / NW;  // 16-channel output tiles per wavefront
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
+  const __bf16* src = a.in + img * (long)(kPix * kCh);
+  const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // weight fragments: [k-step][n-tile][lane][8]; prefetched PF k-steps ahead
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) + (long)wave * WN * 64 + lane;
+  constexpr int WSTEP = 16 * 64;
+  bf16x8 w0[WN], w1[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    w0[nt] = wp[nt * 64];
+    if constexpr (PF == 2) w1[nt] = wp[WSTEP + nt * 64];
+  }
+  wp += PF * WSTEP;
+
+  if constexpr (ABL != 1) stage_image<NW>(lds, src, av, wave, lane);
+  if (a.residual) {  // whole rows, 16 bytes per lane: coalesced in global memory and in LDS
+    const __bf16* rs = a.residual + (long)b * (kPix * kCh);
+#pragma unroll
+    for (int j = 0; j < kPix * 32 / (64 * NW); ++j) {
+      const int u = tid + 64 * NW * j, pix = u >> 5, c16 = u & 31;
+      *reinterpret_cast<bf16x8*>(ldsB + pix * kRowB + c16 * 16) = *reinterpret_cast<const bf16x8*>(rs + u * 8);
+    }
+  }
+
+  f32x4 acc[kMT][WN];
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS byte address of this lane's operand pixel in each 16-pixel tile for a tap; lanes whose
+  // tap falls outside the image read a zero pixel on the same bank group as the real one
+  auto tap_addresses = [&](int tap, int (&addr)[kMT]) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      const int m = mt * 16 + r16;
+      const int py = m / kSide, px = m - py * kSide;
+      const bool ok = (unsigned)(py + dy - 1) < (unsigned)kSide && (unsigned)(px + dx - 1) < (unsigned)kSide;
+      const int q = m + (dy - 1) * kSide + (dx - 1);
+      addr[mt] = kq * kPlaneB + (ok ? q : kPix + (q & 15)) * 16;
+    }
+  };
+  constexpr int KOFF = 4 * kPlaneB;  // LDS bytes between consecutive 32-channel k-steps
+
+  int aaddr[kMT];
+  tap_addresses(0, aaddr);
+  __syncthreads();
+  bf16x8 afA[kMT], afB[kMT];
+#pragma unroll
+  for (int mt = 0; mt < kMT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt]);
+
+  // Software pipeline, one k-step deep for the LDS operand and PF deep for the weights: each
+  // step first issues the loads of LATER steps, then runs its 18 MFMAs on registers that were
+  // loaded a whole step ago.  sched_barrier keeps hipcc from sinking the loads back down to
+  // their uses (it otherwise waits for every ds_read right before the MFMA that needs it).
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    int anext[kMT];
+    tap_addresses(tap < 8 ? tap + 1 : 8, anext);
+#pragma unroll
+    for (int kc = 0; kc < kKC; ++kc) {
+      bf16x8(&cur)[kMT] = (kc & 1) ? afB : afA;
+      bf16x8(&nxt)[kMT] = (kc & 1) ? afA : afB;
+      bf16x8 w2[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];  // PF k-steps ahead (the buffer is padded)
+      wp += WSTEP;
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+        nxt[mt] = *reinterpret_cast<const bf16x8*>(lds + (kc < kKC - 1 ? aaddr[mt] + (kc + 1) * KOFF : anext[mt]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        if constexpr (PF == 2) {
+          w0[nt] = w1[nt];
+          w1[nt] = w2[nt];
+        } else {
+          w0[nt] = w2[nt];
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) aaddr[mt] = anext[mt];
+  }
+
+  if constexpr (ABL == 2) {  // timing-only build: keep the accumulators alive, store one value
+    float t = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+    if (t == 12345.678f) a.out[0] = (__bf16)t;
+    return;
+  }
+
+  // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16); add bias and
+  // the residual (from LDS), apply ReLU, round to bf16 and park the result in LDS region B
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int cbase = (wave * WN + nt) * 16 + kq * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      char* slot = ldsB + (mt * 16 + r16) * kRowB + cbase * 2;
+      float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
+      float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
+      if (a.residual) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
+        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+      }
+      if (a.relu) {
+        v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+      }
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+      const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+      *reinterpret_cast<bf16x4*>(slot) = ov;
+    }
+    if (a.mean_out) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
+      }
+      if (r16 == 0) {
+        const float inv = 1.0f / (float)kPix;
+        *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) = make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
+      }
+    }
+  }
+  __syncthreads();
+  // epilogue, part 2: the finished image leaves LDS as whole 512-byte rows, 16 bytes per lane
+  __bf16* dst = a.out + (long)b * (kPix * kCh);
+#pragma unroll
+  for (int j = 0; j < kPix * 32 / (64 * NW); ++j) {
+    const int u = tid + 64 * NW * j, pix = u >> 5, c16 = u & 31;
+    *reinterpret_cast<bf16x8*>(dst + u * 8) = *reinterpret_cast<const bf16x8*>(ldsB + pix * kRowB + c16 * 16);
+  }
+}
+
+template <int NW, int PF, int ABL = 0>
+int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
+  static bool configured = false;
+  auto kern = conv_trunk_kernel<NW, PF, ABL>;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
+    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv_trunk: LDS attribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(64 * NW), kLdsTotal, stream, a);
+  return mz::check_launch("mz_conv3x3_bf16 (trunk)");
+}
+
+}  // namespace
+
+namespace mz {
+// called by mz_conv3x3_bf16 for the 12x12x256->256 stride-1 shape
+int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                    const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream) {
+  TrunkArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
+              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
+  static const int abl = getenv("MZ_TRUNK_ABLATE") ? atoi(getenv("MZ_TRUNK_ABLATE")) : 0;
+  if (abl == 1) return launch_trunk<8, 2, 1>(a, B, stream);  // timing only: no staging
+  if (abl == 2) return launch_trunk<8, 2, 2>(a, B, stream);  // timing only: no epilogue
+  return launch_trunk<8, 2>(a, B, stream);
+}
+}  // namespace mz
