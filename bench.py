@@ -71,24 +71,38 @@ def cpu_baseline(cfg, sd, sims, budget_s=20.0):
                       f"A={cfg.action_space_size}, torch fp32 CPU nets with {threads} threads"}
 
 
-def measure_trunk_kernel(net, B, iters=40):
-    """Average duration of the dominant kernel (12x12 256->256 conv with residual + ReLU) at
-    the workload's batch, HIP events on the launch stream."""
-    from muzero_amd import mfma
-    layer = net.dyn_blocks[0][1]
-    x = torch.randn(B, 12, 12, 256, device=net.device).to(torch.bfloat16)
-    res = torch.randn(B, 12, 12, 256, device=net.device).to(torch.bfloat16)
-    out = torch.empty_like(x)
+def measure_dynamics_kernel(worker, iters=30):
+    """Average duration of the dominant kernel - the fused dynamics chain (5 convolutions
+    12x12x256->256 with the image resident in LDS) - at the workload's batch, timed with HIP
+    events on the stream it is launched on, on the hidden states of the last search."""
+    net, m = worker.net, worker.mcts
+    B = worker.B
+    mean = torch.empty(B, net.W, dtype=torch.float32, device=net.device)
+    out = torch.empty_like(m.pool[0])
+    slot = torch.randint(0, m.steps, (B,), dtype=torch.int32, device=net.device)
+    acts = torch.randint(0, net.A, (B,), dtype=torch.int32, device=net.device)
     for _ in range(3):
-        mfma.conv(layer, x, out, B, 12, 12, True, res, None, 0, None, None, None)
+        net.dynamics(m.pool, slot, B, acts, out, mean)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        mfma.conv(layer, x, out, B, 12, 12, True, res, None, 0, None, None, None)
+        net.dynamics(m.pool, slot, B, acts, out, mean)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3  # seconds
+    n_convs = 1 + 2 * len(net.dyn_blocks)
+    return e0.elapsed_time(e1) / iters * 1e-3, n_convs  # seconds per launch, convolutions per launch
+
+
+def load_profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the last rocprofv3 PMC passes
+    (FETCH_SIZE / WRITE_SIZE, corrected as documented in profiles/); None if never profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -188,12 +202,18 @@ def main():
             "env_steps_per_sec": world * B * args.steps / elapsed,
             "visit_sum_check": visits_ok,
         }
-        dur = measure_trunk_kernel(net, B)
-        achieved = TRUNK_FLOPS * B / dur / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_bf16 12x12x256->256 (residual+ReLU)",
+        dur, n_convs = measure_dynamics_kernel(worker)
+        flops = TRUNK_FLOPS * n_convs * B
+        achieved = flops / dur / 1e12
+        prof = load_profiled_traffic()
+        traffic = None
+        if prof and prof.get("games_per_gpu") == B:
+            traffic = prof.get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": f"conv_chain_kernel: dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
                            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                           "launch_us": dur * 1e6, "flops_per_launch": TRUNK_FLOPS * B,
+                           "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                           "launch_us": dur * 1e6, "flops_per_launch": flops,
                            "end_to_end_frac": sims_per_s / world * 953.98e6 / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args.sims, args.cpu_seconds)

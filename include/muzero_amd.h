@@ -157,6 +157,25 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
                     const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
                     int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream);
 
+/* A chain of 12x12 256->256 convolutions fused into one kernel with the image
+ * resident in LDS: the whole dynamics network (conv_state, bn, resblocks;
+ * model.py:236-241) or the 12x12 tail of the representation network
+ * (model.py:201-202 and the last downsample stage's blocks).  Layer l reads
+ * image buffer l%2 and writes buffer (l+1)%2; add_residual adds what the
+ * destination buffer still holds (the input of the residual block's first
+ * convolution) before the ReLU.  wpk / bias as for mz_conv3x3_bf16.  in_slot,
+ * action_vec + actions and mean_out as for mz_conv3x3_bf16 (applied to the
+ * first layer's input and the last layer's output).  n_layers <= 20. */
+typedef struct mz_chain_layer {
+  const void* wpk;
+  const float* bias;
+  int32_t relu;
+  int32_t add_residual;
+} mz_chain_layer;
+int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                       int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                       float* mean_out, int32_t B, mz_stream_t stream);
+
 /* x.mean(dim=(2,3)) (model.py:243, :275): float NHWC [B][HW][C] -> [B][C]. */
 int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
 

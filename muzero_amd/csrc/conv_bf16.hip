@@ -16,14 +16,15 @@
 // Fused: folded-BatchNorm bias, residual add, ReLU, the dynamics network's
 // "hidden + conv1x1(one-hot action)" prologue, the gather of parent hidden
 // states from the node pool, and the spatial mean for the heads.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace mz {
 int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
                     const void* residual, void* out, const float* action_vec, const int32_t* actions,
                     float* mean_out, int32_t B, int32_t relu, hipStream_t stream);
+int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                    int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                    int32_t B, hipStream_t stream);
 }
 
 namespace {
@@ -249,11 +250,6 @@ using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, true, 2>;       // representa
 using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, true, 2>;    // downsample.0.conv
 using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, true, 2>;    // downsample.0.blocks
 using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, true, 2>;   // downsample.1.conv
-using ConvTrunk = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 1>;
-// experimental trunk variants (selected with MZ_TRUNK_VARIANT)
-using ConvTrunkV1 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 4, 2, 8>;  // 8 waves, <=128 regs, 2 WG/CU
-using ConvTrunkV2 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, false, 2, 2, 8>;  // 8 waves, <=256 regs, 1 WG/CU
-using ConvTrunkV3 = Cfg<256, 256, 256, 1, 12, 12, 12, 12, true, 1, 2, 4>;   // 4 waves, halo, 512 regs, 1 WG/CU // every 256ch 12x12 layer
 
 template <class C>
 bool matches(int H, int W, int Cin, int Cout, int stride) {
@@ -271,7 +267,7 @@ int mz_conv3x3_bf16_info(int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_
   else if (matches<ConvDown0>(H, W, Cin, Cout, stride)) cc = ConvDown0::CINC;
   else if (matches<ConvMid>(H, W, Cin, Cout, stride)) cc = ConvMid::CINC;
   else if (matches<ConvDown1>(H, W, Cin, Cout, stride)) cc = ConvDown1::CINC;
-  else if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) { cc = ConvTrunk::CINC; whole = 1; }
+  else if (H == 12 && W == 12 && Cin == 256 && Cout == 256 && stride == 1) { cc = 256; whole = 1; }
   else
     return mz::fail(MZ_E_ARG, "conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
                     Cout, stride);
@@ -289,16 +285,9 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   ConvArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
   hipStream_t s = mz::as_stream(stream);
-  if (matches<ConvTrunk>(H, W, Cin, Cout, stride)) {
-    static const int variant = getenv("MZ_TRUNK_VARIANT") ? atoi(getenv("MZ_TRUNK_VARIANT")) : 0;
-    if (variant == 4)
-      return mz::conv_trunk_bf16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out,
-                                 B, relu, s);
-    if (variant == 1) return launch<ConvTrunkV1>(a, B, s);
-    if (variant == 2) return launch<ConvTrunkV2>(a, B, s);
-    if (variant == 3) return launch<ConvTrunkV3>(a, B, s);
-    return launch<ConvTrunk>(a, B, s);
-  }
+  if (H == 12 && W == 12 && Cin == 256 && Cout == 256 && stride == 1)  // the trunk shape has its own kernel
+    return mz::conv_trunk_bf16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B,
+                               relu, s);
   MZ_REQUIRE(mean_out == nullptr, "mz_conv3x3_bf16: the fused spatial mean needs a whole-image kernel");
   if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch<ConvStem>(a, B, s);
   if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch<ConvDown0>(a, B, s);
@@ -306,6 +295,18 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<ConvDown1>(a, B, s);
   return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
                   Cout, stride);
+}
+
+int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                       int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                       float* mean_out, int32_t B, mz_stream_t stream) {
+  MZ_REQUIRE(in && layers && out && B > 0, "mz_conv_chain_bf16: null tensor or empty batch");
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= 20, "mz_conv_chain_bf16: n_layers must be 1..20 (got %d)", n_layers);
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv_chain_bf16: action_vec and actions go together");
+  for (int l = 0; l < n_layers; ++l) MZ_REQUIRE(layers[l].wpk && layers[l].bias, "mz_conv_chain_bf16: layer %d is null", l);
+  MZ_REQUIRE(!layers[0].add_residual, "mz_conv_chain_bf16: the first layer has no residual source");
+  return mz::conv_chain_bf16(in, in_slot, slot_stride, layers, n_layers, out, action_vec, actions, mean_out, B,
+                             mz::as_stream(stream));
 }
 
 }  // extern "C"

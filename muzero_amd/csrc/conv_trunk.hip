@@ -10,10 +10,8 @@
 // tap shift, which makes each ds_read_b128 lane group conflict-free (a
 // pixel-major layout, padded or not, always puts two lanes of a group on one
 // bank group because half of the group reads the next channel chunk).  Pixels
-// 144..159 of every plane are zero: lanes whose tap falls outside the image read
-// pixel 144 instead of being masked.
-#include <cstdlib>
-
+// 144..159 of every plane are zero: a lane whose tap falls outside the image reads
+// the zero pixel that shares a bank group with the pixel it would have read.
 #include "common.h"
 
 namespace {
@@ -76,7 +74,7 @@ constexpr int kRowB = kCh * 2 + 16;
 constexpr int kOutBytes = kPix * kRowB;           // 76 032
 constexpr int kLdsTotal = kLdsBytes + kOutBytes;  // 157 952 of the CU's 163 840
 
-template <int NW, int PF, int ABL = 0>
+template <int NW, int PF>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldsB = lds + kLdsBytes;
@@ -100,7 +98,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   }
   wp += PF * WSTEP;
 
-  if constexpr (ABL != 1) stage_image<NW>(lds, src, av, wave, lane);
+  stage_image<NW>(lds, src, av, wave, lane);
   if (a.residual) {  // whole rows, 16 bytes per lane: coalesced in global memory and in LDS
     const __bf16* rs = a.residual + (long)b * (kPix * kCh);
 #pragma unroll
@@ -178,16 +176,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
     for (int mt = 0; mt < kMT; ++mt) aaddr[mt] = anext[mt];
   }
 
-  if constexpr (ABL == 2) {  // timing-only build: keep the accumulators alive, store one value
-    float t = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < kMT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < WN; ++nt) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
-    if (t == 12345.678f) a.out[0] = (__bf16)t;
-    return;
-  }
-
   // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16); add bias and
   // the residual (from LDS), apply ReLU, round to bf16 and park the result in LDS region B
 #pragma unroll
@@ -232,10 +220,223 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   }
 }
 
-template <int NW, int PF, int ABL = 0>
+// ---------------------------------------------------------------------------
+// Fused chain of trunk convolutions: the whole dynamics network (conv_state + its
+// residual blocks, model.py:236-241) or the representation network's 12x12 tail
+// run as ONE kernel with the image resident in LDS from the first layer to the
+// last.  Two planar image buffers fill the CU's 160 KiB of LDS: layer l reads
+// buffer l%2 and writes buffer (l+1)%2; the second convolution of a residual block
+// finds the block's input still sitting in its destination buffer and adds it in
+// place.  Per image the kernel reads 72 KB and writes 72 KB of HBM instead of
+// (2..3 x 72 KB) per layer, has no per-layer launch, and needs one workgroup
+// barrier per layer.  Workgroups are persistent: each walks images b, b+grid, ...
+// ---------------------------------------------------------------------------
+constexpr int kMaxChain = 20;
+
+struct ChainArgs {
+  const __bf16* in;
+  const int* in_slot;
+  int slot_stride;
+  __bf16* out;
+  const float* avec;
+  const int* actions;
+  float* mean_out;
+  int B;
+  int n_layers;
+  const __bf16* wpk[kMaxChain];
+  const float* bias[kMaxChain];
+  unsigned relu_mask;  // bit l: ReLU after layer l
+  unsigned res_mask;   // bit l: add the destination buffer's content (residual) before the ReLU
+};
+
+template <int NW, int PF>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int WN = 16 / NW;
+  constexpr int WSTEP = 16 * 64;
+  constexpr int KOFF = 4 * kPlaneB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  auto tap_addresses = [&](int tap, int (&addr)[kMT]) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      const int m = mt * 16 + r16;
+      const int py = m / kSide, px = m - py * kSide;
+      const bool ok = (unsigned)(py + dy - 1) < (unsigned)kSide && (unsigned)(px + dx - 1) < (unsigned)kSide;
+      const int q = m + (dy - 1) * kSide + (dx - 1);
+      addr[mt] = kq * kPlaneB + (ok ? q : kPix + (q & 15)) * 16;
+    }
+  };
+
+  // zero pixels of both buffers (never written afterwards)
+  {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64) {
+      const int buf = s >> 9, r = s & 511;
+      *reinterpret_cast<bf16x8*>(lds + buf * kLdsBytes + (r >> 4) * kPlaneB + (kPix + (r & 15)) * 16) = z;
+    }
+  }
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
+    const __bf16* src = a.in + img * (long)(kPix * kCh);
+    const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
+
+    // first layer's weights are requested before the image so that both are in flight together
+    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk[0]) + (long)wave * WN * 64 + lane;
+    bf16x8 w0[WN], w1[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+      w0[nt] = wp[nt * 64];
+      if constexpr (PF == 2) w1[nt] = wp[WSTEP + nt * 64];
+    }
+    wp += PF * WSTEP;
+
+    {  // image -> buffer 0 (planar); 72 blocks of (16 pixels x 4 channel chunks)
+      const int pl = lane & 15, qq = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
+        if (av) {
+          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+          v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
+          v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
+          v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
+          v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+        }
+        *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v;
+      }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+      const char* sbuf = lds + (l & 1) * kLdsBytes;
+      char* dbuf = lds + ((l + 1) & 1) * kLdsBytes;
+      const bool last = l == a.n_layers - 1;
+
+      f32x4 acc[kMT][WN];
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+      int aaddr[kMT];
+      tap_addresses(0, aaddr);
+      bf16x8 afA[kMT], afB[kMT];
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt]);
+
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int kc = 0; kc < kKC; ++kc) {
+          bf16x8(&cur)[kMT] = (kc & 1) ? afB : afA;
+          bf16x8(&nxt)[kMT] = (kc & 1) ? afA : afB;
+          bf16x8 w2[WN];
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];
+          wp += WSTEP;
+          if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, aaddr);  // the next step is the next tap's first
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt)
+            nxt[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            if constexpr (PF == 2) {
+              w0[nt] = w1[nt];
+              w1[nt] = w2[nt];
+            } else {
+              w0[nt] = w2[nt];
+            }
+          }
+        }
+      }
+
+      // next layer's first weight fragments travel while this layer's epilogue runs
+      const float* bias = a.bias[l];
+      const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
+      if (!last) {
+        wp = reinterpret_cast<const bf16x8*>(a.wpk[l + 1]) + (long)wave * WN * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          w0[nt] = wp[nt * 64];
+          if constexpr (PF == 2) w1[nt] = wp[WSTEP + nt * 64];
+        }
+        wp += PF * WSTEP;
+      }
+
+      // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
+      // mt*16 + r16; the result goes to the destination buffer in the planar layout
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        const int cbase = (wave * WN + nt) * 16 + kq * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + cbase);
+        char* plane = dbuf + (cbase >> 3) * kPlaneB + (cbase & 4) * 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+          char* slot = plane + (mt * 16 + r16) * 16;
+          float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
+          float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
+          if (res) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
+            v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+          }
+          if (relu) {
+            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          }
+          s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+          const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+          *reinterpret_cast<bf16x4*>(slot) = ov;
+        }
+        if (last && a.mean_out) {
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
+          }
+          if (r16 == 0) {
+            const float inv = 1.0f / (float)kPix;
+            *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
+                make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    {  // final buffer -> global, same (16 pixels x 4 chunks) blocks as the load
+      const char* fbuf = lds + (a.n_layers & 1) * kLdsBytes;
+      __bf16* dst = a.out + (long)b * (kPix * kCh);
+      const int pl = lane & 15, qq = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        *reinterpret_cast<bf16x8*>(dst + pix * kCh + q * 8) = *reinterpret_cast<const bf16x8*>(fbuf + q * kPlaneB + pix * 16);
+      }
+    }
+    __syncthreads();  // the next image overwrites buffer 0
+  }
+}
+
+template <int NW, int PF>
 int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
   static bool configured = false;
-  auto kern = conv_trunk_kernel<NW, PF, ABL>;
+  auto kern = conv_trunk_kernel<NW, PF>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
@@ -255,9 +456,46 @@ int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
                     float* mean_out, int32_t B, int32_t relu, hipStream_t stream) {
   TrunkArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
               static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
-  static const int abl = getenv("MZ_TRUNK_ABLATE") ? atoi(getenv("MZ_TRUNK_ABLATE")) : 0;
-  if (abl == 1) return launch_trunk<8, 2, 1>(a, B, stream);  // timing only: no staging
-  if (abl == 2) return launch_trunk<8, 2, 2>(a, B, stream);  // timing only: no epilogue
   return launch_trunk<8, 2>(a, B, stream);
+}
+int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                    int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                    int32_t B, hipStream_t stream) {
+  ChainArgs a{};
+  a.in = static_cast<const __bf16*>(in);
+  a.in_slot = in_slot;
+  a.slot_stride = slot_stride;
+  a.out = static_cast<__bf16*>(out);
+  a.avec = action_vec;
+  a.actions = actions;
+  a.mean_out = mean_out;
+  a.B = B;
+  a.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    a.wpk[l] = static_cast<const __bf16*>(layers[l].wpk);
+    a.bias[l] = layers[l].bias;
+    if (layers[l].relu) a.relu_mask |= 1u << l;
+    if (layers[l].add_residual) a.res_mask |= 1u << l;
+  }
+  static bool configured = false;
+  auto kern = conv_chain_kernel<8, 2>;
+  constexpr int lds = 2 * kLdsBytes;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv_chain: LDS attribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    n_cu = n;
+  }
+  const int grid = B < n_cu ? B : n_cu;  // one persistent workgroup per CU (all of its LDS)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  return mz::check_launch("mz_conv_chain_bf16");
 }
 }  // namespace mz

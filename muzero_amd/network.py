@@ -185,6 +185,7 @@ class MuZeroNetwork:
         self.W = config.num_channels
         self.cin = config.observation_shape[0]
         self._buffers: Dict[tuple, torch.Tensor] = {}
+        self._chains: Dict[str, tuple] = {}
         self.input_hw = tuple(input_hw)
         self.load_state_dict(state_dict if state_dict is not None else init_state_dict(config, seed))
 
@@ -213,6 +214,7 @@ class MuZeroNetwork:
         self.reward_head = Head(sd, "dynamics.reward_head", self.device)
         if not (self.policy.hidden == self.value_head.hidden == self.reward_head.hidden):
             raise NotImplementedError("the three heads must share one hidden width")
+        self._chains = {}
         self._upload_all()
 
     def state_dict(self):
@@ -279,6 +281,29 @@ class MuZeroNetwork:
             mfma.conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride,
                       self.action_vec if actions is not None else None, actions, mean_out)
 
+    def _chain_ok(self, convs, H, W) -> bool:
+        """True when the fused LDS-resident chain kernel serves these layers."""
+        return (self.precision == "bf16" and H == 12 and W == 12 and 1 <= len(convs) <= 20
+                and all(c.cin == 256 and c.cout == 256 and c.stride == 1 for c in convs))
+
+    def _chain(self, key, blocks, first, x, out, in_slot=None, slot_stride=0, actions=None, mean_out=None):
+        """[first conv] + residual blocks as ONE kernel (mz_conv_chain_bf16)."""
+        cached = self._chains.get(key)
+        if cached is None:
+            specs = []
+            if first is not None:
+                specs.append((first, 1, 0))
+            for c1, c2 in blocks:
+                specs += [(c1, 1, 0), (c2, 1, 1)]
+            arr = (_lib.ChainLayer * len(specs))()
+            for i, (c, relu, res) in enumerate(specs):
+                arr[i] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), relu, res)
+            cached = self._chains[key] = (arr, len(specs))
+        arr, n = cached
+        _lib.call("mz_conv_chain_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
+                  _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
+                  _lib.ptr(mean_out), out.shape[0], _lib.current_stream())
+
     def _res_block(self, blk, x, tmp, out, H, W, mean_out=None):
         """out = relu(conv2(relu(conv1(x))) + x); out may alias nothing but x's pool slot."""
         self._conv(blk[0], x, tmp, H, W, relu=True)
@@ -318,24 +343,40 @@ class MuZeroNetwork:
         """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W]."""
         B, H, W, _ = obs_nhwc.shape
         x = obs_nhwc
-        last = len(self.rep_plan) - 1
-        for i, (kind, item) in enumerate(self.rep_plan):
+        plan = self.rep_plan
+        # the trailing residual blocks at the hidden resolution run as one fused chain
+        n_tail = 0
+        while n_tail < len(plan) and plan[len(plan) - 1 - n_tail][0] == "res":
+            n_tail += 1
+        hh, hw = self.hidden_hw(H, W)
+        tail = [item for _, item in plan[len(plan) - n_tail:]]
+        fuse = n_tail > 0 and self._chain_ok([c for blk in tail for c in blk], hh, hw)
+        head = plan[:len(plan) - n_tail] if fuse else plan
+        last = len(plan) - 1
+        for i, (kind, item) in enumerate(head):
+            final = i == last
             if kind == "conv":
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-                y = hidden_out if i == last else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
-                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if i == last else None)
+                y = hidden_out if final else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
+                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None)
                 x, H, W = y, HO, WO
             else:
                 c = item[0].cout
                 tmp = self._buf(("rep_tmp", H), (B, H, W, c))
-                y = hidden_out if i == last else self._buf(("rep", i % 3), (B, H, W, c))
-                self._res_block(item, x, tmp, y, H, W, mean_out=mean_out if i == last else None)
+                y = hidden_out if final else self._buf(("rep", i % 3), (B, H, W, c))
+                self._res_block(item, x, tmp, y, H, W, mean_out=mean_out if final else None)
                 x = y
+        if fuse:
+            self._chain("rep_tail", tail, None, x, hidden_out, mean_out=mean_out)
 
     def dynamics(self, pool: torch.Tensor, in_slot: Optional[torch.Tensor], slot_stride: int,
                  actions: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
         """hidden' = dynamics(pool[in_slot[b]*slot_stride + b], actions[b]) for every b."""
         B, H, W, c = hidden_out.shape
+        if self._chain_ok([self.dyn_first] + [l for blk in self.dyn_blocks for l in blk], H, W):
+            self._chain("dynamics", self.dyn_blocks, self.dyn_first, pool, hidden_out, in_slot, slot_stride,
+                        actions, mean_out)
+            return
         a = self._buf("dyn_a", (B, H, W, c))
         t = self._buf("dyn_t", (B, H, W, c))
         cur, spare = a, self._buf("dyn_b", (B, H, W, c))

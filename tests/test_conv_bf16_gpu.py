@@ -75,3 +75,47 @@ def test_unsupported_shape_is_an_error():
     from muzero_amd import _lib, mfma
     with pytest.raises(_lib.MuZeroAmdError, match="no MFMA kernel"):
         mfma.kernel_info(10, 10, 64, 64, 1)
+
+
+def test_fused_chain_matches_layer_by_layer():
+    """mz_conv_chain_bf16 (image resident in LDS across layers) against the same layers run
+    one kernel at a time, and against a PyTorch fp32 reference of the chain."""
+    import ctypes as C
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(7)
+    B, n_blocks = 6, 2
+    convs = []
+    for _ in range(1 + 2 * n_blocks):
+        w = torch.randn(256, 256, 3, 3, generator=g) / (3 * 16.0)
+        b = torch.randn(256, generator=g) * 0.1
+        convs.append((w, b, mfma.pack_weights(w, 256).cuda(), b.cuda()))
+    pool = torch.randn(3 * B, 12, 12, 256, generator=g).to(torch.bfloat16).cuda()
+    slot = torch.randint(0, 3, (B,), generator=g, dtype=torch.int32).cuda()
+    acts = torch.randint(0, 5, (B,), generator=g, dtype=torch.int32).cuda()
+    avec = (torch.randn(5, 256, generator=g) * 0.5).cuda()
+    specs = [(0, 1, 0)] + [(1 + 2 * j + k, 1, k) for j in range(n_blocks) for k in (0, 1)]
+    arr = (_lib.ChainLayer * len(specs))()
+    for i, (ci, relu, res) in enumerate(specs):
+        arr[i] = _lib.ChainLayer(convs[ci][2].data_ptr(), convs[ci][3].data_ptr(), relu, res)
+    out = torch.empty(B, 12, 12, 256, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(B, 256, dtype=torch.float32, device="cuda")
+    _lib.call("mz_conv_chain_bf16", _lib.ptr(pool), _lib.ptr(slot), B, arr, len(specs), _lib.ptr(out),
+              _lib.ptr(avec), _lib.ptr(acts), _lib.ptr(mean), B, _lib.current_stream())
+    torch.cuda.synchronize()
+
+    # PyTorch fp32 reference with bf16 rounding of activations between layers
+    import torch.nn.functional as F
+    x = torch.stack([pool[int(slot[b]) * B + b] for b in range(B)]).float().cpu()
+    x = (x + avec.cpu()[acts.cpu().long()].view(B, 1, 1, 256)).to(torch.bfloat16).float()
+    rnd = lambda t: t.to(torch.bfloat16).float()
+    conv = lambda t, i: F.conv2d(t.permute(0, 3, 1, 2), rnd(convs[i][0]), convs[i][1], padding=1).permute(0, 2, 3, 1)
+    x = rnd(F.relu(conv(x, 0)))
+    for j in range(n_blocks):
+        t = rnd(F.relu(conv(x, 1 + 2 * j)))
+        y = F.relu(conv(t, 2 + 2 * j) + x)
+        last_f32 = y
+        x = rnd(y)
+    got = out.float().cpu()
+    scale = x.abs().mean().item()
+    assert ((got - x).abs() <= 0.02 * x.abs() + 0.02 * scale).all(), (got - x).abs().max().item()
+    np.testing.assert_allclose(mean.cpu().numpy(), last_f32.mean(dim=(1, 2)).numpy(), rtol=5e-3, atol=5e-3 * scale)

@@ -43,8 +43,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
     flops = 2.0 * B * HO * HO * cout * cin * 9
-    import os
-    print(f"{args.shape} variant={os.environ.get('MZ_TRUNK_VARIANT', '0')} B={B}: {ms * 1e3:.1f} us/launch, {flops / ms / 1e9:.1f} TFLOP/s")
+    print(f"{args.shape} B={B}: {ms * 1e3:.1f} us/launch, {flops / ms / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
