@@ -47,28 +47,24 @@ struct ConvArgs {
   int relu;
 };
 
-template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, bool HALO_, int MINW_, int PF_ = 2,
-          int NW_ = 4>
+template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, int MINW_, int PF_ = 2, int NW_ = 4>
 struct Cfg {
   static constexpr int NW = NW_;          // wavefronts per workgroup; they split the output channels
   static constexpr int THREADS = 64 * NW_;
   static constexpr int PF = PF_;  // weight prefetch distance in k-steps (1 or 2)
   static constexpr int CIN = CIN_, CINC = CINC_, COUT = COUT_, S = S_, TH = TH_, TW = TW_, HIN = HIN_, WIN = WIN_;
-  static constexpr bool HALO = HALO_;
   static constexpr int MINW = MINW_;
   static constexpr int HO = (HIN - 1) / S + 1, WO = (WIN - 1) / S + 1;
   static constexpr int PY = HO / TH, PX = WO / TW;
   static constexpr int M = TH * TW, MT = (M + 15) / 16;
-  static constexpr int IH = HALO ? (TH - 1) * S + 3 : TH, IW = HALO ? (TW - 1) * S + 3 : TW;
+  static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;  // input window incl. the halo
   static constexpr int ROWB = CINC * 2 + 16;
   static constexpr int KC = CINC / 32, NCC = CIN / CINC;
   static constexpr int NTILES = COUT / 16, WN = NTILES / NW;
-  static constexpr int ZROW = IH * IW;  // index of the all-zero row (no-halo variant)
-  static constexpr int LDS_BYTES = (IH * IW + (HALO ? 0 : 1)) * ROWB;
+  static constexpr int LDS_BYTES = IH * IW * ROWB;
   static constexpr int KSTEPS = NCC * 9 * KC;
   static_assert(HO % TH == 0 && WO % TW == 0, "patches must tile the output");
   static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % (16 * NW) == 0, "channel tiling");
-  static_assert(HALO || (S == 1 && TH == HIN && TW == WIN), "no-halo variant needs the whole image in LDS");
 };
 
 template <class C>
@@ -95,12 +91,6 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
     }
     *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = v;
   }
-  if constexpr (!C::HALO) {
-    if (tid <= UPP) {
-      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      *reinterpret_cast<bf16x8*>(lds + C::ZROW * C::ROWB + tid * 16) = z;
-    }
-  }
 }
 
 template <class C>
@@ -114,7 +104,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
   const __bf16* src = a.in + img * (long)C::HIN * C::WIN * C::CIN;
   const float* av = a.avec ? a.avec + (long)a.actions[b] * C::CIN : nullptr;
-  const int iy0 = C::HALO ? oy0 * C::S - 1 : 0, ix0 = C::HALO ? ox0 * C::S - 1 : 0;
+  const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;
   const int r16 = lane & 15, kq = lane >> 4;
 
   f32x4 acc[MT][WN];
@@ -134,50 +124,62 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   }
   wp += C::PF * WSTEP;
 
+  // LDS byte address of this lane's pixel (tap 0, first k-step) in each 16-pixel tile; every
+  // other tap / k-step is a compile-time offset from it, so it rides in the ds_read immediate
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = mt * 16 + r16;
+    if (m >= C::M) m = C::M - 1;  // padding rows recompute the last pixel; never stored
+    const int py = m / C::TW, px = m % C::TW;
+    abase[mt] = (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16;
+  }
+  constexpr int NS = 9 * KC;  // k-steps per channel chunk
+  auto step_offset = [](int st) {
+    const int tap = st / KC, kc = st % KC;
+    return ((tap / 3) * C::IW + tap % 3) * C::ROWB + kc * 64;
+  };
+
   for (int cc = 0; cc < C::NCC; ++cc) {
     if (cc > 0) __syncthreads();
     stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
     __syncthreads();
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const int toff = C::HALO ? (dy * C::IW + dx) * C::ROWB : ((dy - 1) * C::IW + (dx - 1)) * C::ROWB;
-      // per-lane LDS byte address of this lane's pixel in each 16-pixel M tile, for this tap
-      // (recomputed per tap: 9 taps x MT cheap integer ops instead of 2*MT live registers)
-      int aaddr[MT];
+    // software pipeline: the LDS operand of step st+1 is read while step st's MFMAs run
+    bf16x8 afA[MT], afB[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int m = mt * 16 + r16;
-        if (m >= C::M) m = C::M - 1;  // padding rows recompute the last pixel; never stored
-        const int py = m / C::TW, px = m % C::TW;
-        aaddr[mt] = (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16 + toff;
-        if constexpr (!C::HALO) {
-          const bool ok = (unsigned)(py + dy - 1) < (unsigned)C::TH && (unsigned)(px + dx - 1) < (unsigned)C::TW;
-          if (!ok) aaddr[mt] = C::ZROW * C::ROWB + kq * 16;
-        }
-      }
+    for (int mt = 0; mt < MT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(lds + abase[mt]);
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        bf16x8 w2[WN];
+    for (int st = 0; st < NS; ++st) {
+      bf16x8(&cur)[MT] = (st & 1) ? afB : afA;
+      bf16x8(&nxt)[MT] = (st & 1) ? afA : afB;
+      bf16x8 w2[WN];
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];  // PF k-steps ahead (the buffer is padded)
-        wp += WSTEP;
-        bf16x8 af[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt] + kc * 64);
+      for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];  // PF k-steps ahead (the buffer is padded)
+      wp += WSTEP;
+      if (st + 1 < NS) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+          nxt[mt] = *reinterpret_cast<const bf16x8*>(lds + abase[mt] + step_offset(st + 1));
+      }
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], af[mt], acc[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-          if constexpr (C::PF == 2) {
-            w0[nt] = w1[nt];
-            w1[nt] = w2[nt];
-          } else {
-            w0[nt] = w2[nt];
-          }
+        for (int nt = 0; nt < WN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        if constexpr (C::PF == 2) {
+          w0[nt] = w1[nt];
+          w1[nt] = w2[nt];
+        } else {
+          w0[nt] = w2[nt];
         }
       }
     }
@@ -245,11 +247,11 @@ int launch(const ConvArgs& a, int B, hipStream_t stream) {
 }
 
 // The reference architecture's five convolution shapes (model.py:178-215 with the
-// default config).           CIN CINC COUT S  TH  TW  HIN WIN halo  waves/SIMD
-using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, true, 2>;       // representation.conv1
-using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, true, 2>;    // downsample.0.conv
-using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, true, 2>;    // downsample.0.blocks
-using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, true, 2>;   // downsample.1.conv
+// default config) other than the 12x12 trunk.  CIN CINC COUT S TH TW HIN WIN waves/SIMD
+using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2>;       // representation.conv1
+using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, 2>;    // downsample.0.conv
+using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, 2>;    // downsample.0.blocks
+using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, 2>;   // downsample.1.conv
 
 template <class C>
 bool matches(int H, int W, int Cin, int Cout, int stride) {

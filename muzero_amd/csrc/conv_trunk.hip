@@ -347,12 +347,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt)
             nxt[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
-          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+          // issue order inside the step: the two weight loads, then one LDS read of the NEXT
+          // step behind every pair of MFMAs of this one (measured +2.5 % over loads-then-MFMAs)
+          __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
+#pragma unroll
+          for (int i = 0; i < kMT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {

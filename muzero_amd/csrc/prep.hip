@@ -57,6 +57,47 @@ __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* _
   }
 }
 
+// Fast path of the same conversion for 3*D a multiple of 8 and HW a multiple of 64: every
+// global access is 16 bytes per lane (the byte-at-a-time version above is bound by the
+// number of memory instructions, not by bytes).
+template <typename OutT>
+__global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned char* __restrict__ ring,
+                                                             OutT* __restrict__ out, int D, int HW, int newest) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned char* st = reinterpret_cast<unsigned char*>(smem);  // [D][192]
+  const int b = blockIdx.y, p0 = blockIdx.x * kPix;
+  constexpr int row = kPix * 3;  // 192 bytes = 12 x 16
+  for (int u = threadIdx.x; u < D * 12; u += 256) {
+    const int f = u / 12, part = u - f * 12;
+    const int slot = (newest + 1 + f) % D;
+    *reinterpret_cast<uint4*>(st + f * row + part * 16) =
+        *reinterpret_cast<const uint4*>(ring + (((long)b * D + slot) * HW + p0) * 3 + part * 16);
+  }
+  __syncthreads();
+  const int C = 3 * D, cpp = C / 8;  // 16-byte (bf16) output chunks per pixel
+  for (int ch = threadIdx.x; ch < kPix * cpp; ch += 256) {
+    const int px = ch / cpp, c0 = (ch - px * cpp) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j, f = c / 3, r = c - f * 3;
+      v[j] = (float)st[f * row + px * 3 + r] / 255.0f;
+    }
+    const long o = ((long)b * HW + p0 + px) * C + c0;
+    if constexpr (sizeof(OutT) == 2) {
+      uint4 pk;
+      pk.x = f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
+      pk.y = f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
+      pk.z = f32_to_bf16_rne(v[4]) | ((unsigned)f32_to_bf16_rne(v[5]) << 16);
+      pk.w = f32_to_bf16_rne(v[6]) | ((unsigned)f32_to_bf16_rne(v[7]) << 16);
+      *reinterpret_cast<uint4*>(out + o) = pk;
+    } else {
+      *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 // uint8 NHWC [B][HW][C] -> float32 NCHW [B][C][HW], x / 255 (train.py:534-540)
 __global__ void prepare_observation_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int C,
                                            int HW) {
@@ -97,6 +138,15 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
   const size_t lds = (size_t)D * kPix * 3;
   MZ_REQUIRE(lds <= 64 * 1024, "mz_ring_to_obs: ring depth %d too large", D);
   const dim3 grid((HW + kPix - 1) / kPix, B);
+  if ((3 * D) % 8 == 0 && HW % kPix == 0) {
+    if (out_is_bf16)
+      hipLaunchKernelGGL(ring_to_obs_vec_kernel<unsigned short>, grid, dim3(256), lds, mz::as_stream(stream), ring,
+                         static_cast<unsigned short*>(out), D, HW, newest_slot);
+    else
+      hipLaunchKernelGGL(ring_to_obs_vec_kernel<float>, grid, dim3(256), lds, mz::as_stream(stream), ring,
+                         static_cast<float*>(out), D, HW, newest_slot);
+    return mz::check_launch("mz_ring_to_obs");
+  }
   if (out_is_bf16)
     hipLaunchKernelGGL(ring_to_obs_kernel<unsigned short>, grid, dim3(256), lds, mz::as_stream(stream), ring,
                        static_cast<unsigned short*>(out), D, HW, newest_slot);

@@ -15,12 +15,45 @@ class L:
     pass
 
 
+def bench_chain(n_layers, B, iters):
+    """The fused LDS-resident chain of 12x12x256->256 convolutions (mz_conv_chain_bf16)."""
+    import os
+    from muzero_amd import _lib
+    keep = []
+    arr = (_lib.ChainLayer * n_layers)()
+    for l in range(n_layers):
+        w = mfma.pack_weights(torch.randn(256, 256, 3, 3) / 48.0, 256).cuda()
+        b = (torch.randn(256) * 0.1).cuda()
+        keep += [w, b]
+        arr[l] = _lib.ChainLayer(w.data_ptr(), b.data_ptr(), 1, 1 if (l % 2 == 0 and l > 0) else 0)
+    x = torch.randn(B, 12, 12, 256, device="cuda").to(torch.bfloat16)
+    out = torch.empty_like(x)
+    mean = torch.empty(B, 256, device="cuda")
+    run = lambda: _lib.call("mz_conv_chain_bf16", _lib.ptr(x), None, 0, arr, n_layers, _lib.ptr(out), None, None,
+                            _lib.ptr(mean), B, _lib.current_stream())
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * 144 * 256 * 2304 * n_layers
+    print(f"chain{n_layers} variant={os.environ.get('MZ_CHAIN_VARIANT', '0')} B={B}: {ms * 1e3:.1f} us/launch "
+          f"({ms * 1e3 / n_layers:.1f} us/layer), {flops / ms / 1e9:.1f} TFLOP/s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="trunk")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
+    if args.shape.startswith("chain"):
+        return bench_chain(int(args.shape[5:] or 5), args.batch, args.iters)
     H, cin, cout, stride = SHAPES[args.shape]
     B = args.batch
     layer = L()
