@@ -200,6 +200,8 @@ def main():
                        "sims_per_move": args.sims, "wave": args.wave, "parallelism": f"games sharded x{world}",
                        "hip_graph": bool(args.graph), "frames_from_host": bool(args.from_host)},
             "env_steps_per_sec": world * B * args.steps / elapsed,
+            # ALE "-v5" environments repeat each action over 4 emulator frames (built-in frameskip)
+            "env_frames_per_sec": 4 * world * B * args.steps / elapsed,
             "visit_sum_check": visits_ok,
         }
         dur, n_convs = measure_dynamics_kernel(worker)

@@ -185,12 +185,17 @@ int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int3
  *   w2p[(t*(Hd/4) + ks)*64 + lane] = W2[t*16 + lane%16][4*ks + lane/16]   (ceil(O/16) tiles,
  *                                                       rows >= O are zero)
  * with W1 [Hd][C], W2 [O][Hd] the torch Linear weights; b1 float [Hd];
- * b2 float [ceil(O/16)*16] zero padded. */
+ * b2 float [ceil(O/16)*16] zero padded.  With bf16 != 0 the two weight buffers
+ * hold bf16 fragments for the 16x16x32 MFMA instead (throughput precision):
+ *   w1p[(t*(C/32) + ks)*64 + lane][j] = W1[t*16 + lane%16][32*ks + 8*(lane/16) + j]
+ * (same for w2p with Hd); C and Hd must then be multiples of 32. */
 typedef struct mz_head_weights {
-  const float* w1p;
+  const void* w1p;
   const float* b1;
-  const float* w2p;
+  const void* w2p;
   const float* b2;
+  int32_t bf16;
+  int32_t reserved;
 } mz_head_weights;
 
 /* Policy, value and (optional) reward heads on the spatial mean [B][C], fused

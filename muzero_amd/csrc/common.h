@@ -27,6 +27,36 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(mz_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+constexpr int kMaxDevices = 64;
+
+inline int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
+
+// Raise a kernel's dynamic-LDS limit once per device (needed above 64 KiB).  `done` is a
+// per-kernel array of kMaxDevices flags.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, bool* done, const char* what) {
+  const int dev = current_device();
+  if (done[dev]) return MZ_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return fail(MZ_E_LAUNCH, "%s: LDS attribute: %s", what, hipGetErrorString(e));
+  done[dev] = true;
+  return MZ_OK;
+}
+
+inline int compute_units() {
+  static int cached[kMaxDevices] = {0};
+  const int dev = current_device();
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 }  // namespace mz
 
 #define MZ_REQUIRE(cond, ...) \

@@ -234,14 +234,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
 
 template <class C>
 int launch(const ConvArgs& a, int B, hipStream_t stream) {
-  static bool configured = false;
+  static bool configured[mz::kMaxDevices] = {false};
   auto kern = conv3x3_bf16_kernel<C>;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv3x3_bf16: LDS attribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, configured, "conv3x3_bf16"))
+    return rc;
   hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), C::LDS_BYTES, stream, a);
   return mz::check_launch("mz_conv3x3_bf16");
 }

@@ -442,14 +442,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 
 template <int NW, int PF>
 int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
-  static bool configured = false;
+  static bool configured[mz::kMaxDevices] = {false};
   auto kern = conv_trunk_kernel<NW, PF>;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTotal);
-    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv_trunk: LDS attribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsTotal, configured, "conv_trunk")) return rc;
   hipLaunchKernelGGL(kern, dim3(B), dim3(64 * NW), kLdsTotal, stream, a);
   return mz::check_launch("mz_conv3x3_bf16 (trunk)");
 }
@@ -484,23 +479,11 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
     if (layers[l].relu) a.relu_mask |= 1u << l;
     if (layers[l].add_residual) a.res_mask |= 1u << l;
   }
-  static bool configured = false;
+  static bool configured[mz::kMaxDevices] = {false};
   auto kern = conv_chain_kernel<8, 2>;
   constexpr int lds = 2 * kLdsBytes;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return mz::fail(MZ_E_LAUNCH, "conv_chain: LDS attribute: %s", hipGetErrorString(e));
-    configured = true;
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    n_cu = n;
-  }
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain")) return rc;
+  const int n_cu = mz::compute_units();
   const int grid = B < n_cu ? B : n_cu;  // one persistent workgroup per CU (all of its LDS)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   return mz::check_launch("mz_conv_chain_bf16");

@@ -94,6 +94,7 @@ struct HeadW {
   const float* w2p;  // [ceil(O/16)][Hd/4][64]
   const float* b2;   // [ceil(O/16)*16]  (zero padded)
   int out;           // O: number of outputs of this head
+  int bf16;          // w1p / w2p hold bf16 fragments for the 16x16x32 MFMA instead
 };
 
 // softmax over the (up to 64) logits held one per lane of a wavefront
@@ -206,6 +207,37 @@ __device__ __forceinline__ void dense16(const float* __restrict__ wp, const floa
   }
 }
 
+// the same layer on the bf16 matrix cores (throughput precision): weights are bf16 fragments
+// [out tile][K/32][lane][8] (lane l: W[tile*16 + l%16][32*kstep + 8*(l/16) + j]); the 16
+// samples are converted from the float32 LDS copy on the fly; float32 accumulation
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, const float* __restrict__ bias,
+                                             const float* src, int lds, float* dst, int ldd, int K, int tiles,
+                                             bool relu) {
+  constexpr int NW = kHeadsBlock / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ks_n = K / 32;
+  const float* sp = src + (lane & 15) * lds + (lane >> 4) * 8;
+  for (int t = wave; t < tiles; t += NW) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const hbf16x8* w = wp + (long)t * ks_n * 64 + lane;
+    for (int ks = 0; ks < ks_n; ++ks) {
+      hbf16x8 bfrag;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bfrag[j] = (__bf16)sp[ks * 32 + j];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(long)ks * 64], bfrag, acc, 0, 0, 0);
+    }
+    const int o = t * 16 + (lane >> 4) * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + o);
+    float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
+    if (relu) {
+      v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+    }
+    float* d = dst + (lane & 15) * ldd + o;
+    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+  }
+}
+
 __device__ __forceinline__ void dense16_any(const float* wp, const float* bias, const float* src, int lds,
                                             float* dst, int ldd, int K, int tiles, bool relu) {
   if (K % 32 == 0) dense16<8>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
@@ -231,9 +263,11 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
   }
   __syncthreads();
-  dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  else dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   __syncthreads();
-  dense16_any(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  else dense16_any(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,13 +376,15 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
   MZ_REQUIRE((reward_w == nullptr) == (reward == nullptr), "mz_heads: reward weights and output go together");
   MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && S >= 1, "mz_heads: bad sizes");
   MZ_REQUIRE(C > 0 && C % 4 == 0 && Hd > 0 && Hd % 16 == 0, "mz_heads: C must be a multiple of 4 and Hd of 16");
+  for (const mz_head_weights* h : {policy, value_w, reward_w})
+    MZ_REQUIRE(!h || !h->bf16 || (C % 32 == 0 && Hd % 32 == 0), "mz_heads: bf16 weights need C and Hd multiples of 32");
   const int O = 2 * S + 1;
   const int omax = ((O > A ? O : A) + 15) / 16 * 16;
   const size_t lds = (size_t)kHeadSamples * ((Hd + 1) + (C > omax ? C + 1 : omax + 1)) * sizeof(float);
   MZ_REQUIRE(lds <= 64 * 1024, "mz_heads: layer sizes exceed the LDS budget");
   auto cvt = [](const mz_head_weights* h, int out) {
-    HeadW r{nullptr, nullptr, nullptr, nullptr, out};
-    if (h) r = HeadW{h->w1p, h->b1, h->w2p, h->b2, out};
+    HeadW r{nullptr, nullptr, nullptr, nullptr, out, 0};
+    if (h) r = HeadW{static_cast<const float*>(h->w1p), h->b1, static_cast<const float*>(h->w2p), h->b2, out, h->bf16};
     return r;
   };
   hipLaunchKernelGGL(heads_kernel, dim3((B + kHeadSamples - 1) / kHeadSamples, reward_w ? 3 : 2),

@@ -146,8 +146,18 @@ def _pack_linear(w: torch.Tensor) -> torch.Tensor:
     return wp.view(tiles, 16, K // 4, 4).permute(0, 2, 3, 1).contiguous().view(-1)
 
 
+def _pack_linear_bf16(w: torch.Tensor) -> torch.Tensor:
+    """torch Linear weight [O][K] -> bf16 MFMA fragments [ceil(O/16)][K/32][lane = kq*16 + r][8]
+    holding W[tile*16 + r][32*kstep + 8*kq + j]; rows beyond O are zero."""
+    O, K = w.shape
+    tiles = (O + 15) // 16
+    wp = torch.zeros(tiles * 16, K, dtype=torch.float32)
+    wp[:O] = w.float()
+    return wp.to(torch.bfloat16).view(tiles, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
 class Head:
-    def __init__(self, sd, name: str, device):
+    def __init__(self, sd, name: str, device, bf16: bool = False):
         keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
         if len(keys) != 2:
             raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
@@ -156,17 +166,21 @@ class Head:
         self.hidden, self.out = w1.shape[0], w2.shape[0]
         if self.hidden % 16 or w1.shape[1] % 4:
             raise NotImplementedError(f"{name}: hidden width must be a multiple of 16 and the input of 4")
-        self.w1p = _pack_linear(w1).to(device)
+        bf16 = bf16 and self.hidden % 32 == 0 and w1.shape[1] % 32 == 0
+        pack = _pack_linear_bf16 if bf16 else _pack_linear
+        self.w1p = pack(w1).to(device)
         self.b1 = sd[f"{name}.{k1}.bias"].float().contiguous().to(device)
-        self.w2p = _pack_linear(w2).to(device)
+        self.w2p = pack(w2).to(device)
         b2 = torch.zeros((self.out + 15) // 16 * 16)
         b2[:self.out] = sd[f"{name}.{k2}.bias"].float()
         self.b2 = b2.to(device)
-        self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr())
+        self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr(),
+                              1 if bf16 else 0, 0)
 
 
 class _HeadWeights(C.Structure):
-    _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p)]
+    _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p),
+                ("bf16", C.c_int32), ("reserved", C.c_int32)]
 
 
 # --------------------------------------------------------------------------- network
@@ -209,9 +223,10 @@ class MuZeroNetwork:
         self.dyn_blocks = [self._res(sd, f"dynamics.resblocks.{j}") for j in range(cfg.num_blocks)]
         wa = sd["dynamics.conv_action.weight"].float()[:, :, 0, 0]          # [W][A]
         self.action_vec = (wa.t() + sd["dynamics.conv_action.bias"].float()).contiguous().to(self.device)  # [A][W]
-        self.policy = Head(sd, "prediction.policy_head", self.device)
-        self.value_head = Head(sd, "prediction.value_head", self.device)
-        self.reward_head = Head(sd, "dynamics.reward_head", self.device)
+        hb = self.precision == "bf16"  # heads follow the network's precision
+        self.policy = Head(sd, "prediction.policy_head", self.device, hb)
+        self.value_head = Head(sd, "prediction.value_head", self.device, hb)
+        self.reward_head = Head(sd, "dynamics.reward_head", self.device, hb)
         if not (self.policy.hidden == self.value_head.hidden == self.reward_head.hidden):
             raise NotImplementedError("the three heads must share one hidden width")
         self._chains = {}

@@ -36,3 +36,30 @@ def test_layout_query_and_argument_errors():
         _lib.call("mz_tree_layout_query", 4, 65, 51, C.byref(L))
     with pytest.raises(_lib.MuZeroAmdError, match="null"):
         _lib.call("mz_tree_select", None, C.byref(L), None, None, 10, None)
+
+
+def test_argument_validation_needs_no_gpu():
+    """Every entry point rejects bad arguments before touching the device."""
+    L = _lib.TreeLayout()
+    _lib.call("mz_tree_layout_query", 4, 6, 11, C.byref(L))
+    cases = [
+        ("mz_tree_root_init", (None, C.byref(L), None, None, 0.75, 0.25, None), "null"),
+        ("mz_tree_expand_backup", (C.c_void_p(8), C.byref(L), None, None, None, 1, 0.997, None), "null network output"),
+        ("mz_select_action", (None, 4, 6, 1.0, None, None, None), "bad arguments"),
+        ("mz_conv3x3_f32", (None, None, 0) + (None,) * 6 + (1, 12, 12, 8, 8, 1, 1, None), "null tensor"),
+        ("mz_conv3x3_bf16", (None, None, 0) + (None,) * 7 + (1, 12, 12, 256, 256, 1, 1, None), "null tensor"),
+        ("mz_conv_chain_bf16", (C.c_void_p(8), None, 0, None, 5, C.c_void_p(8), None, None, None, 4, None), "null"),
+        ("mz_heads", (None, 4, 256, 256, 6, 300) + (None,) * 10, "null argument"),
+        ("mz_ring_push", (C.c_void_p(8), C.c_void_p(8), 4, 32, 27647, 0, 0, None), "multiple of 16"),
+        ("mz_ring_to_obs", (C.c_void_p(8), C.c_void_p(8), 1, 4, 32, 9216, 32, None), "outside the ring"),
+        ("mz_prepare_observation", (None, None, 1, 96, 9216, None), "bad arguments"),
+        ("mz_support_to_scalar", (None, 4, 300, None, None), "bad arguments"),
+    ]
+    for name, args, msg in cases:
+        with pytest.raises(_lib.MuZeroAmdError, match=msg):
+            _lib.call(name, *args)
+    chunk, whole = C.c_int32(), C.c_int32()
+    with pytest.raises(_lib.MuZeroAmdError, match="no MFMA kernel"):
+        _lib.call("mz_conv3x3_bf16_info", 10, 10, 64, 64, 1, C.byref(chunk), C.byref(whole))
+    _lib.call("mz_conv3x3_bf16_info", 12, 12, 256, 256, 1, C.byref(chunk), C.byref(whole))
+    assert (chunk.value, whole.value) == (256, 1)

@@ -1,0 +1,128 @@
+"""Edge cases of the device path: ragged batch sizes, extreme action counts, full trees,
+error behaviour of the reference surface."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import TableNet, child_hash, load
+
+pytestmark = pytest.mark.gpu
+
+
+def _fake_search(B, A, sims, wave, seed, noisy=True):
+    """Device trees driven by a hash-table network with A actions (table built here)."""
+    from muzero_amd.tree import DeviceTrees
+    from oracle import tree as otree
+    rng = np.random.default_rng(seed)
+    rows = 257
+    logits = rng.normal(0, 1.5, (rows, A)).astype(np.float32)
+    pri = np.exp(logits - logits.max(1, keepdims=True))
+    pri = (pri / pri.sum(1, keepdims=True)).astype(np.float32)
+    val = rng.normal(0, 3, rows).astype(np.float32)
+    rew = rng.normal(0, 1, rows).astype(np.float32)
+    root_hash = rng.integers(1, 2147483647, size=B).astype(np.int64)
+    noise = rng.dirichlet(np.full(A, 0.3), size=B) if noisy and A > 1 else None
+    steps = sims // wave
+    trees = DeviceTrees(B, A, steps + 1, max_visits=sims)
+    node_hash = np.zeros((B, steps + 1), np.int64)
+    node_hash[:, 0] = root_hash
+    trees.root_init(torch.from_numpy(pri[root_hash % rows]).cuda(),
+                    None if noise is None else torch.from_numpy(noise).cuda(), 0.25)
+    ar = np.arange(B)
+    for s in range(steps):
+        trees.select()
+        parent = trees.array("leaf_parent").cpu().numpy()
+        act = trees.array("leaf_action").cpu().numpy()
+        kid = child_hash(node_hash[ar, parent], act.astype(np.int64))
+        node_hash[:, s + 1] = kid
+        r = kid % rows
+        trees.expand_backup(torch.from_numpy(pri[r]).cuda(), torch.from_numpy(val[r]).cuda(),
+                            torch.from_numpy(rew[r]).cuda(), wave, 0.997)
+    visits, root_value, probs = (t.cpu().numpy() for t in trees.readout())
+    assert int(trees.array("status").abs().sum()) == 0
+
+    def infer(hiddens, actions):
+        out = []
+        for h, a in zip(hiddens, actions):
+            k = int(child_hash(int(h), int(a)))
+            out.append((pri[k % rows], float(val[k % rows]), float(rew[k % rows]), k))
+        return out
+    for b in range(B):
+        root, _ = otree.search(pri[root_hash[b] % rows], int(root_hash[b]), infer, sims, wave,
+                               noise=None if noise is None else noise[b])
+        assert otree.visit_counts(root).tolist() == visits[b].tolist(), (B, A, b)
+        assert root.q() == root_value[b]
+        assert otree.action_probs(root).tolist() == probs[b].tolist()
+
+
+@pytest.mark.parametrize("B,A,sims,wave", [(1, 6, 50, 1), (3, 18, 20, 1), (5, 1, 12, 1), (7, 64, 30, 1),
+                                           (2, 2, 64, 1), (6, 33, 40, 4)])
+def test_ragged_batches_and_extreme_action_counts(B, A, sims, wave):
+    _fake_search(B, A, sims, wave, seed=B * 100 + A)
+
+
+def test_full_tree_is_reported_not_overrun():
+    from muzero_amd.tree import DeviceTrees
+    B, A = 2, 4
+    trees = DeviceTrees(B, A, 3, max_visits=10)   # room for the root + 2 expansions
+    pri = torch.full((B, A), 0.25, device="cuda")
+    z = torch.zeros(B, device="cuda")
+    trees.root_init(pri, None)
+    for _ in range(2):
+        trees.select()
+        trees.expand_backup(pri, z, z, 1, 0.997)
+    assert trees.array("num_nodes").tolist() == [3, 3] and trees.array("status").tolist() == [0, 0]
+    trees.select()
+    trees.expand_backup(pri, z, z, 1, 0.997)      # no free node: flagged, nothing written out of range
+    torch.cuda.synchronize()
+    assert trees.array("status").tolist() == [2, 2]
+    assert trees.array("num_nodes").tolist() == [3, 3]
+    assert trees.array("root_visit").tolist() == [2, 2]
+
+
+def test_select_action_ties_and_zero_temperature():
+    from muzero_amd.tree import select_actions
+    counts = torch.tensor([[0, 5, 5, 0], [7, 7, 7, 7], [0, 0, 0, 9], [1, 0, 0, 0]], dtype=torch.int32, device="cuda")
+    assert select_actions(counts, 0.0).tolist() == [1, 0, 3, 0]              # first maximum (np.argmax)
+    u = torch.tensor([0.0, 0.999999, 0.5, 0.3], dtype=torch.float64, device="cuda")
+    assert select_actions(counts, 1.0, u).tolist() == [1, 3, 3, 0]           # zero-count actions never drawn
+
+
+def test_run_on_unexpanded_root_raises_like_the_reference():
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.search import MCTS, MinMaxStats, Node
+    cfg = MuZeroConfig()
+    with pytest.raises(IndexError):
+        MCTS(cfg).run(Node(0, None), 6, None, MinMaxStats())
+
+
+@pytest.mark.parametrize("B", [1, 37, 300])
+def test_chain_kernel_any_batch(B):
+    """Persistent workgroups: fewer images than CUs, and a count that does not divide evenly."""
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(B)
+    w = [mfma.pack_weights(torch.randn(256, 256, 3, 3, generator=g) / 48.0, 256).cuda() for _ in range(3)]
+    bias = [(torch.randn(256, generator=g) * 0.1).cuda() for _ in range(3)]
+    x = torch.randn(B, 12, 12, 256, generator=g).to(torch.bfloat16).cuda()
+    arr = (_lib.ChainLayer * 3)()
+    for i in range(3):
+        arr[i] = _lib.ChainLayer(w[i].data_ptr(), bias[i].data_ptr(), 1, 1 if i == 2 else 0)
+    out = torch.empty_like(x)
+    _lib.call("mz_conv_chain_bf16", _lib.ptr(x), None, 0, arr, 3, _lib.ptr(out), None, None, None, B,
+              _lib.current_stream())
+    # layer by layer with the single-layer kernel
+    class L:
+        pass
+    t = [torch.empty_like(x) for _ in range(3)]
+    src, res = x, None
+    for i in range(3):
+        layer = L()
+        layer.cin = layer.cout = 256
+        layer.stride = 1
+        layer.dev = {"w": w[i], "bias": bias[i]}
+        mfma.conv(layer, src, t[i], B, 12, 12, True, t[0] if i == 2 else None, None, 0, None, None, None)
+        src = t[i]
+    torch.cuda.synchronize()
+    assert torch.equal(out, t[2])      # same arithmetic in both kernels: bit-identical
