@@ -27,10 +27,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 WORKLOADS = {
-    # name: (actions, games per GPU, description)          BASELINE.json configs[2] / [1] / [3]
-    "synthetic18": (18, 1024, "synthetic 96x96 obs (32 RGB frames), 18 actions, 1024 games x 50 sims per GPU"),
-    "pong6": (6, 256, "Pong-shaped: 96x96 obs (32 RGB frames), 6 actions, 256 games x 50 sims per GPU"),
-    "mspacman9": (9, 512, "MsPacman-shaped: 96x96 obs (32 RGB frames), 9 actions, 512 games x 50 sims per GPU"),
+    # name: (actions, games per GPU, label)                 BASELINE.json configs[2] / [1] / [3]
+    "synthetic18": (18, 1024, "synthetic"),
+    "pong6": (6, 256, "Pong-shaped"),
+    "mspacman9": (9, 512, "MsPacman-shaped"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X
 # convolution FLOPs (2*MACs) per sample: representation 5 181 014 016, one recurrent inference
@@ -129,19 +129,22 @@ def main():
     rank, world, local = mzdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("MZ_FORCE_DEVICE") is not None:  # rehearsal of N ranks on one GPU (with MZ_DIST_BACKEND=gloo)
+        local = int(os.environ["MZ_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    A, B, desc = WORKLOADS[args.workload]
+    A, B, label = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
+    desc = f"{label} 96x96 obs (32 RGB frames), {A} actions, {B} games x {args.sims} sims per GPU"
     cfg = MuZeroConfig()
     cfg.action_space_size = A
     cfg.num_simulations = args.sims
 
     # weights: created on rank 0, handed to the other ranks with one RCCL broadcast
     sd = init_state_dict(cfg, seed=0 if rank == 0 else 1 + rank, randomize_bn=True)
-    sd = mzdist.broadcast_state_dict(sd, src=0, device=device)
+    sd = mzdist.broadcast_state_dict(sd, src=0)
     if not mzdist.verify_same_everywhere(sd):
         raise SystemExit("weight broadcast left ranks with different parameters")
     net = MuZeroNetwork(cfg, precision="bf16", device=device, state_dict=sd)
@@ -182,10 +185,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert actions.shape == (B,)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mzdist.max_over_ranks(elapsed)
     visits_ok = int(worker.mcts.visits.sum().item()) == B * args.sims
 
     if rank == 0:

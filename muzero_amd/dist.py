@@ -27,7 +27,8 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MZ_DIST_BACKEND=gloo lets several ranks rehearse on one GPU (RCCL wants one GPU per rank)
+            backend = os.environ.get("MZ_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -91,3 +92,13 @@ def verify_same_everywhere(sd) -> bool:
     gathered = [None] * dist.get_world_size()
     dist.all_gather_object(gathered, digest)
     return all(g == gathered[0] for g in gathered)
+
+
+def max_over_ranks(value: float) -> float:
+    """MAX all-reduce of a host scalar (on the GPU for RCCL, on the CPU for gloo)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
