@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 WORKLOADS = {
-    # name: (actions, games per GPU, label)                 BASELINE.json configs[2] / [1] / [3]
+    # name: (actions, games per GPU, label)
     "synthetic18": (18, 1024, "synthetic"),
     "pong6": (6, 256, "Pong-shaped"),
     "mspacman9": (9, 512, "MsPacman-shaped"),
