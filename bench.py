@@ -71,27 +71,19 @@ def cpu_baseline(cfg, sd, sims, budget_s=20.0):
                       f"A={cfg.action_space_size}, torch fp32 CPU nets with {threads} threads"}
 
 
-def measure_dynamics_kernel(worker, iters=30):
+def measure_dynamics_kernel(worker, one_step, moves=2):
     """Average duration of the dominant kernel - the fused dynamics chain (5 convolutions
-    12x12x256->256 with the image resident in LDS) - at the workload's batch, timed with HIP
-    events on the stream it is launched on, on the hidden states of the last search."""
-    net, m = worker.net, worker.mcts
-    B = worker.B
-    mean = torch.empty(B, net.W, dtype=torch.float32, device=net.device)
-    out = torch.empty_like(m.pool[0])
-    slot = torch.randint(0, m.steps, (B,), dtype=torch.int32, device=net.device)
-    acts = torch.randint(0, net.A, (B,), dtype=torch.int32, device=net.device)
-    for _ in range(3):
-        net.dynamics(m.pool, slot, B, acts, out, mean)
+    12x12x256->256 with the image resident in LDS) - measured in place: HIP events on the launch
+    stream around every dynamics launch of `moves` further moves of the same workload."""
+    net = worker.net
+    net.dynamics_events = []
+    for _ in range(moves):
+        one_step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        net.dynamics(m.pool, slot, B, acts, out, mean)
-    e1.record()
-    torch.cuda.synchronize()
+    pairs, net.dynamics_events = net.dynamics_events, None
+    total_ms = sum(e0.elapsed_time(e1) for e0, e1 in pairs)
     n_convs = 1 + 2 * len(net.dyn_blocks)
-    return e0.elapsed_time(e1) / iters * 1e-3, n_convs  # seconds per launch, convolutions per launch
+    return total_ms / len(pairs) * 1e-3, n_convs, len(pairs)  # s per launch, convs per launch, launches
 
 
 def load_profiled_traffic():
@@ -204,7 +196,7 @@ def main():
             "env_frames_per_sec": 4 * world * B * args.steps / elapsed,
             "visit_sum_check": visits_ok,
         }
-        dur, n_convs = measure_dynamics_kernel(worker)
+        dur, n_convs, n_launches = measure_dynamics_kernel(worker, lambda: worker.step(env.step())[0])
         flops = TRUNK_FLOPS * n_convs * B
         achieved = flops / dur / 1e12
         prof = load_profiled_traffic()
@@ -215,7 +207,7 @@ def main():
                            "kernel": f"conv_chain_kernel: dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
                            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                           "launch_us": dur * 1e6, "flops_per_launch": flops,
+                           "launch_us": dur * 1e6, "launches_timed": n_launches, "flops_per_launch": flops,
                            "end_to_end_frac": sims_per_s / world * 953.98e6 / (PEAK_BF16_TFLOPS * 1e12)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args.sims, args.cpu_seconds)

@@ -185,50 +185,44 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
     }
   }
 
-  // epilogue: lane holds channels cbase..cbase+3 of pixel (mt*16 + r16)
-  float msum[WN][4];
+  // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16).  Bias,
+  // residual, ReLU and the bf16 rounding happen here; the tile is parked in LDS (the input
+  // window is dead by now) so that it can leave as whole rows
+  constexpr int OROW = C::COUT * 2 + 16;
+  static_assert(C::M * OROW <= C::LDS_BYTES, "output tile must fit in the input window's LDS");
+  __syncthreads();
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int cbase = (wave * WN + nt) * 16 + kq * 4;
     const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
-    msum[nt][0] = msum[nt][1] = msum[nt][2] = msum[nt][3] = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = mt * 16 + r16;
       if (m < C::M) {
-        const int py = m / C::TW, px = m % C::TW;
-        const long o = (((long)b * C::HO + oy0 + py) * C::WO + ox0 + px) * C::COUT + cbase;
         float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
         float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
         if (a.residual) {
+          const int py = m / C::TW, px = m % C::TW;
+          const long o = (((long)b * C::HO + oy0 + py) * C::WO + ox0 + px) * C::COUT + cbase;
           const bf16x4 r = *reinterpret_cast<const bf16x4*>(a.residual + o);
           v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
         }
         if (a.relu) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
-        msum[nt][0] += v0; msum[nt][1] += v1; msum[nt][2] += v2; msum[nt][3] += v3;
         const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-        *reinterpret_cast<bf16x4*>(a.out + o) = ov;
+        *reinterpret_cast<bf16x4*>(lds + m * OROW + cbase * 2) = ov;
       }
     }
   }
-  if (a.mean_out) {  // host guarantees the patch is the whole image
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = msum[nt][r];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        msum[nt][r] = s;
-      }
-      if (r16 == 0) {
-        const int cbase = (wave * WN + nt) * 16 + kq * 4;
-        const float inv = 1.0f / (float)C::M;
-        *reinterpret_cast<float4*>(a.mean_out + (long)b * C::COUT + cbase) =
-            make_float4(msum[nt][0] * inv, msum[nt][1] * inv, msum[nt][2] * inv, msum[nt][3] * inv);
-      }
-    }
+  __syncthreads();
+  // part 2: 16 bytes per lane, consecutive lanes on consecutive channels of a pixel
+  constexpr int UPR = C::COUT / 8;  // 16-byte units per output pixel
+  for (int u = tid; u < C::M * UPR; u += C::THREADS) {
+    const int m = u / UPR, c16 = u % UPR;
+    const int py = m / C::TW, px = m % C::TW;
+    const long o = (((long)b * C::HO + oy0 + py) * C::WO + ox0 + px) * C::COUT + c16 * 8;
+    *reinterpret_cast<bf16x8*>(a.out + o) = *reinterpret_cast<const bf16x8*>(lds + m * OROW + c16 * 16);
   }
 }
 

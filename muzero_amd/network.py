@@ -200,6 +200,7 @@ class MuZeroNetwork:
         self.cin = config.observation_shape[0]
         self._buffers: Dict[tuple, torch.Tensor] = {}
         self._chains: Dict[str, tuple] = {}
+        self.dynamics_events = None  # set to a list to time every fused dynamics launch with HIP events
         self.input_hw = tuple(input_hw)
         self.load_state_dict(state_dict if state_dict is not None else init_state_dict(config, seed))
 
@@ -389,8 +390,15 @@ class MuZeroNetwork:
         """hidden' = dynamics(pool[in_slot[b]*slot_stride + b], actions[b]) for every b."""
         B, H, W, c = hidden_out.shape
         if self._chain_ok([self.dyn_first] + [l for blk in self.dyn_blocks for l in blk], H, W):
+            timing = self.dynamics_events  # optional list: (start, end) event pairs around each launch
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self._chain("dynamics", self.dyn_blocks, self.dyn_first, pool, hidden_out, in_slot, slot_stride,
                         actions, mean_out)
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
             return
         a = self._buf("dyn_a", (B, H, W, c))
         t = self._buf("dyn_t", (B, H, W, c))
