@@ -153,6 +153,7 @@ def main():
         replay = worker.mcts.capture(worker.obs, worker.noise)
 
     def one_step():
+        worker.draw_randomness()  # fresh Dirichlet rows and uniforms every move (host RNG, async copy)
         frames = env.step(on_device=not args.from_host)
         if replay is None:
             return worker.step(frames)[0]

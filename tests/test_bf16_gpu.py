@@ -85,3 +85,28 @@ def test_bf16_search_trees_bit_exact_on_their_own_outputs(A, B, wave):
     torch.cuda.synchronize()
     assert np.array_equal(res.visit_counts.cpu().numpy(), visits)
     assert np.array_equal(res.action_probs.cpu().numpy(), probs)
+
+
+def test_selfplay_worker_evaluate_mode_and_temperature_zero():
+    """The evaluate() flavour of the step (train.py:456-467): no Dirichlet noise, first-maximum
+    action; and the host RNG hooks of the self-play flavour."""
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg, ref, net = _nets(6)
+    B, sims = 5, 20
+    worker = SelfPlayWorker(cfg, net, B, sims)
+    env = SyntheticEnv(B, device="cuda")
+    worker.reset(env.reset())
+    actions, res = worker.step(env.step(), temperature=0, add_noise=False)
+    visits = res.visit_counts.cpu().numpy()
+    assert (visits.sum(1) == sims).all()
+    assert actions.cpu().tolist() == visits.argmax(1).tolist()
+    assert int(worker.mcts.trees.array("root_is_f64").sum()) == 0          # float32 root scores
+    roots = res.roots()
+    assert [roots[0].children[a].visit_count for a in range(6)] == visits[0].tolist()
+    assert roots[0].value() == float(res.root_values[0])
+    assert abs(sum(res.action_prob_dicts()[0].values()) - 1.0) < 1e-12
+    worker.draw_randomness()
+    actions2, res2 = worker.step(env.step(), temperature=1.0, add_noise=True)
+    assert int(worker.mcts.trees.array("root_is_f64").sum()) == B
+    v2 = res2.visit_counts.cpu().numpy()
+    assert all(v2[i, a] > 0 for i, a in enumerate(actions2.cpu().tolist()))   # only visited actions are drawn
