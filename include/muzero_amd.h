@@ -243,6 +243,26 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
 int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,
                            mz_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ * Training side (the callers after the search path).
+ * ------------------------------------------------------------------ */
+
+/* scalar_to_support_loss (model.py:132-140) with scalar_to_support
+ * (model.py:112-129) and transform_value (model.py:84-86) fused: float logits
+ * [n][2S+1], float targets [n] -> loss float [n] = -(two_hot * log_softmax).sum(1)
+ * and, when dlogits != NULL, d loss / d logits float [n][2S+1]. */
+int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,
+                  mz_stream_t stream);
+
+/* Game.make_target / compute_target_value (train.py:89-118) for n_queries positions:
+ * rewards, values double [games][t_max] (padded), n_rewards / n_values int32 [games] their
+ * lengths, (q_game, q_pos) int32 [n_queries].  Outputs [n_queries][K+1]: n-step value targets,
+ * reward targets (0 past the end) and the index of the stored policy to use (-1 = zeros). */
+int mz_nstep_targets(const double* rewards, const double* values, const int32_t* n_rewards,
+                     const int32_t* n_values, int32_t t_max, const int32_t* q_game, const int32_t* q_pos,
+                     int32_t n_queries, int32_t K, int32_t td_steps, double gamma, double* target_values,
+                     double* target_rewards, int32_t* policy_index, mz_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

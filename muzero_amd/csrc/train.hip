@@ -1,0 +1,114 @@
+// Training-side kernels: the support cross-entropy of the unrolled loss
+// (scalar_to_support_loss, model.py:112-140, with transform_value, model.py:84-86) and the
+// n-step value targets (Game.compute_target_value / make_target, train.py:89-118).
+// Compiled with -ffp-contract=off: both restate the reference's rounding sequence.
+#pragma clang fp contract(off)
+
+#include "common.h"
+
+namespace {
+
+// One wavefront per row.  loss = -sum_o t[o] * log_softmax(x)[o] with t the two-hot encoding of
+// the transformed, clamped target; dlogits = softmax(x) * sum(t) - t  (d loss / d x).
+// The two-hot row is built as the reference's two scatter_ calls do: the upper entry is
+// written after the lower one, so when both indices coincide (target clamped at +S) only
+// prob_upper survives.
+__global__ __launch_bounds__(256) void support_ce_kernel(const float* __restrict__ logits,
+                                                        const float* __restrict__ targets, int n, int S,
+                                                        float* __restrict__ loss, float* __restrict__ dlogits) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const int O = 2 * S + 1;
+  const float* x = logits + (long)row * O;
+  const float v = targets[row];
+  const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+  float t = sg * (sqrtf(fabsf(v) + 1.0f) - 1.0f + 0.001f * v);   // transform_value
+  t = fminf(fmaxf(t, (float)-S), (float)S);
+  const float fl = floorf(t);
+  const float p_up = t - fl, p_lo = 1.0f - p_up;
+  int lo = (int)(fl + (float)S);
+  int up = lo + 1;
+  up = up < 0 ? 0 : (up > 2 * S ? 2 * S : up);
+  lo = lo < 0 ? 0 : (lo > 2 * S ? 2 * S : lo);
+  const float t_lo = lo == up ? p_up : p_lo;  // second scatter overwrites the first
+  const float t_sum = lo == up ? p_up : p_lo + p_up;
+
+  float m = -__builtin_inff();
+  for (int o = lane; o < O; o += 64) m = fmaxf(m, x[o]);
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+  float den = 0.f;
+  for (int o = lane; o < O; o += 64) den += expf(x[o] - m);
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) den += __shfl_xor(den, k);
+  const float lse = logf(den);
+  if (lane == 0) {
+    float l = -(t_lo * (x[lo] - m - lse));
+    if (up != lo) l = l - p_up * (x[up] - m - lse);
+    loss[row] = l;
+  }
+  if (dlogits) {
+    float* d = dlogits + (long)row * O;
+    for (int o = lane; o < O; o += 64) {
+      float g = expf(x[o] - m) / den * t_sum;
+      if (o == lo) g -= t_lo;
+      if (o == up && up != lo) g -= p_up;
+      d[o] = g;
+    }
+  }
+}
+
+// One thread per (query, unroll step).  Episode arrays are padded to t_max.
+__global__ void nstep_targets_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
+                                     const int* __restrict__ n_rewards, const int* __restrict__ n_values, int t_max,
+                                     const int* __restrict__ q_game, const int* __restrict__ q_pos, int nq, int K,
+                                     int td, double gamma, double* __restrict__ tv, double* __restrict__ tr,
+                                     int* __restrict__ tp_index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * (K + 1)) return;
+  const int q = i / (K + 1), k = i - q * (K + 1);
+  const int g = q_game[q], cur = q_pos[q] + k;
+  const double* r = rewards + (long)g * t_max;
+  const double* v = values + (long)g * t_max;
+  const int nr = n_rewards[g], nv = n_values[g];
+  double value = 0.0, discount = 1.0;
+  for (int j = 0; j < td; ++j) {  // train.py:92-98
+    const int idx = cur + j;
+    if (idx >= nr) break;
+    value += r[idx] * discount;
+    discount *= gamma;
+  }
+  if (cur + td < nv) value += v[cur + td] * discount;  // train.py:99-100
+  tv[i] = value;
+  tr[i] = cur < nr ? r[cur] : 0.0;                     // train.py:111-116
+  tp_index[i] = cur < nr ? cur : -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,
+                  mz_stream_t stream) {
+  MZ_REQUIRE(logits && targets && loss && n > 0 && S >= 1, "mz_support_ce: bad arguments");
+  hipLaunchKernelGGL(support_ce_kernel, dim3((n + 3) / 4), dim3(256), 0, mz::as_stream(stream), logits, targets, n,
+                     S, loss, dlogits);
+  return mz::check_launch("mz_support_ce");
+}
+
+int mz_nstep_targets(const double* rewards, const double* values, const int32_t* n_rewards,
+                     const int32_t* n_values, int32_t t_max, const int32_t* q_game, const int32_t* q_pos,
+                     int32_t n_queries, int32_t K, int32_t td_steps, double gamma, double* target_values,
+                     double* target_rewards, int32_t* policy_index, mz_stream_t stream) {
+  MZ_REQUIRE(rewards && values && n_rewards && n_values && q_game && q_pos && target_values && target_rewards &&
+                 policy_index,
+             "mz_nstep_targets: null argument");
+  MZ_REQUIRE(t_max > 0 && n_queries > 0 && K >= 0 && td_steps >= 0, "mz_nstep_targets: bad sizes");
+  const int total = n_queries * (K + 1);
+  hipLaunchKernelGGL(nstep_targets_kernel, dim3((total + 255) / 256), dim3(256), 0, mz::as_stream(stream), rewards,
+                     values, n_rewards, n_values, t_max, q_game, q_pos, n_queries, K, td_steps, gamma,
+                     target_values, target_rewards, policy_index);
+  return mz::check_launch("mz_nstep_targets");
+}
+
+}  // extern "C"

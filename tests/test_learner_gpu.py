@@ -1,0 +1,139 @@
+"""Training-side HIP kernels and the device training step against the reference fixtures
+(tests/golden/make_golden_train.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load
+from tests.test_learner_cpu import build_games, check_against_g7, g7_batch, g7_learner
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nstep_targets_bit_exact():
+    from muzero_amd.learner import batched_targets
+    g8 = load("g8_targets")
+    K, td = int(g8["K"]), int(g8["td"])
+    games = build_games(g8)
+    queries = [(gi, s) for gi, g in enumerate(games) for s in range(len(g.rewards))]
+    tv, tr, tp = batched_targets(games, queries, K, td)
+    tv, tr, tp = tv.cpu().numpy(), tr.cpu().numpy(), tp.cpu().numpy()
+    row = 0
+    for gi, g in enumerate(games):
+        n = len(g.rewards)
+        assert np.array_equal(tv[row:row + n], g8[f"g{gi}_tv"])       # float64, same operation order: bit-exact
+        assert np.array_equal(tr[row:row + n], g8[f"g{gi}_tr"])
+        assert np.array_equal(tp[row:row + n], g8[f"g{gi}_tp"])
+        row += n
+    assert row == len(queries)
+
+
+def test_nstep_targets_large_random_against_host():
+    """Size-independent check at a realistic replay size: 512 episodes up to 3000 steps, 4096 queries."""
+    from muzero_amd.learner import GameHistory, batched_targets
+    rng = np.random.default_rng(4)
+    games = []
+    for _ in range(512):
+        T = int(rng.integers(1, 3000))
+        g = GameHistory(6, 0.997)
+        g.rewards = list(rng.normal(0, 1, T))
+        g.values = list(rng.normal(0, 3, T))
+        g.policies = list(rng.dirichlet(np.ones(6), T))
+        games.append(g)
+    queries = [(int(gi), int(rng.integers(0, len(games[gi].rewards)))) for gi in rng.integers(0, 512, 4096)]
+    tv, tr, tp = batched_targets(games, queries, 5, 10)
+    tv, tr, tp = tv.cpu().numpy(), tr.cpu().numpy(), tp.cpu().numpy()
+    for i in range(0, 4096, 7):
+        gi, s = queries[i]
+        for k, (v, r, p) in enumerate(games[gi].make_target(s, 5, 10)):
+            assert tv[i, k] == v and tr[i, k] == r and np.array_equal(tp[i, k], p)
+
+
+def _edge_targets(S):
+    # zeros, signs, exact bin centres, the clamp on both sides (the +S clamp makes both scatter indices coincide)
+    inv = lambda t: np.sign(t) * (((np.sqrt(1 + 4 * 0.001 * (abs(t) + 1 + 0.001)) - 1) / 0.002) ** 2 - 1)
+    vals = [0.0, -0.0, 1e-8, -1e-8, 0.5, -0.5, 3.0, -3.0, inv(S - 0.25), inv(-(S - 0.25)), inv(S + 5.0), inv(-S - 5.0),
+            1e9, -1e9]
+    return np.array(vals, np.float32)
+
+
+@pytest.mark.parametrize("S", [10, 300])
+def test_support_ce_matches_reference_ops(S):
+    from muzero_amd.learner import _support_ce_torch, support_ce_loss
+    rng = np.random.default_rng(S)
+    t = np.concatenate([_edge_targets(S), rng.normal(0, 30, 1000).astype(np.float32)])
+    x = rng.normal(0, 2, (t.size, 2 * S + 1)).astype(np.float32)
+    x[5] += 40 * (rng.random(2 * S + 1) > 0.9)                 # a peaked row
+    xd = torch.tensor(x, device="cuda", requires_grad=True)
+    td = torch.tensor(t, device="cuda")
+    loss = support_ce_loss(xd, td, S, impl="hip")
+    w = torch.tensor(rng.random(t.size).astype(np.float32), device="cuda")
+    (loss * w).sum().backward()
+    # the reference's own op sequence on the CPU, float32
+    xr = torch.tensor(x, requires_grad=True)
+    ref = _support_ce_torch(xr, torch.tensor(t), S)
+    (ref * w.cpu()).sum().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-6)  # softmax - target cancels
+
+
+def test_support_ce_golden_rows():
+    """The g7 fixture's value targets through the kernel against a float64 evaluation of
+    model.py:112-140 on the same rows."""
+    from muzero_amd.learner import support_ce_loss
+    g7 = load("g7_losses")
+    S = 10
+    t = g7["target_rewards"].reshape(-1).astype(np.float32)      # holds the 400.0 that clamps at +S
+    rng = np.random.default_rng(0)
+    x = rng.normal(0, 1, (t.size, 2 * S + 1)).astype(np.float32)
+    got = support_ce_loss(torch.tensor(x, device="cuda"), torch.tensor(t, device="cuda"), S, impl="hip").cpu().numpy()
+    tt = np.clip(np.sign(t) * (np.sqrt(np.abs(t) + 1) - 1 + np.float32(0.001) * t), -S, S).astype(np.float32)
+    fl = np.floor(tt); up_p = tt - fl; lo_p = 1 - up_p
+    lo = np.clip((fl + S).astype(int), 0, 2 * S); up = np.clip((fl + S).astype(int) + 1, 0, 2 * S)
+    sup = np.zeros((t.size, 2 * S + 1))
+    sup[np.arange(t.size), lo] = lo_p
+    sup[np.arange(t.size), up] = up_p
+    x64 = x.astype(np.float64)
+    logp = x64 - x64.max(1, keepdims=True)
+    logp = logp - np.log(np.exp(logp).sum(1, keepdims=True))
+    np.testing.assert_allclose(got, -(sup * logp).sum(1), rtol=1e-5, atol=2e-6)
+
+
+def test_device_training_step_matches_reference():
+    """Whole unrolled loss + backward on the device with the HIP loss: fp32 within 1e-3 of the
+    reference's CPU numbers (losses, per-sample loss, every parameter gradient, BN statistics)."""
+    torch.backends.cudnn.allow_tf32 = False
+    g7 = load("g7_losses")
+    lrn = g7_learner(g7, "cuda", "hip")
+    assert lrn.loss_impl == "hip"
+    check_against_g7(lrn, g7, rtol=1e-3)
+
+
+def test_hip_and_torch_loss_agree_on_device():
+    g7 = load("g7_losses")
+    a, b = g7_learner(g7, "cuda", "hip"), g7_learner(g7, "cuda", "torch")
+    ra = a.update_weights(g7_batch(g7), g7["weights"])
+    rb = b.update_weights(g7_batch(g7), g7["weights"])
+    np.testing.assert_allclose(ra["priorities"], rb["priorities"], rtol=1e-5)
+    for (k, pa), (_, pb) in zip(a.network.state_dict().items(), b.network.state_dict().items()):
+        np.testing.assert_allclose(pa.cpu().numpy(), pb.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_trained_weights_reach_the_search_engine():
+    """After an update the learner's state_dict loads into the inference engine, whose fp32
+    outputs equal the learner network's own eval-mode outputs."""
+    from muzero_amd.network import MuZeroNetwork
+    g7 = load("g7_losses")
+    lrn = g7_learner(g7, "cuda", "hip")
+    for _ in range(3):
+        lrn.update_weights(g7_batch(g7), g7["weights"])
+    sd = lrn.state_dict()
+    eng = MuZeroNetwork(lrn.config, precision="fp32", device="cuda", state_dict=sd)
+    obs = torch.tensor(g7["obs"], device="cuda").permute(0, 3, 1, 2).float() / 255.0
+    out = eng.initial_inference(obs)
+    lrn.network.eval()
+    with torch.no_grad():
+        h, p, v = lrn.network.initial(obs)
+    lrn.network.train()
+    np.testing.assert_allclose(out.policy_logits.cpu().numpy(), p.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(out.hidden_state.cpu().numpy(), h.cpu().numpy(), rtol=1e-3, atol=1e-4)
