@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, checkpoint
 
 
 # --------------------------------------------------------------------------- modules
@@ -299,6 +299,9 @@ class ReplayBuffer:
     def save_game(self, game: GameHistory, priorities: Optional[np.ndarray] = None) -> None:
         if priorities is None:
             priorities = np.full(len(game.rewards), max(self.priorities) if self.priorities else 1)
+        if len(priorities) != len(game.rewards):
+            raise ValueError(f"{len(priorities)} priorities for a game of {len(game.rewards)} positions: the buffer "
+                             "keeps exactly one per position (sampling maps flat indices through game lengths)")
         self.buffer.append(game)
         self.priorities.extend(priorities)
         while len(self.buffer) > self.window_size:
@@ -362,6 +365,23 @@ class Learner:
 
     def state_dict(self):
         return {k: v.detach().cpu() for k, v in self.network.state_dict().items()}
+
+    def save_checkpoint(self, path: str) -> None:
+        """The reference's checkpoint dictionary (train.py:481-495)."""
+        checkpoint.write(path, self.training_step, self.network, self.optimizer, self.scheduler, self.config)
+
+    @classmethod
+    def from_checkpoint(cls, path: str, device="cuda", loss_impl: Optional[str] = None) -> "Learner":
+        """Resume from a checkpoint written by the reference or by ``save_checkpoint``:
+        weights, BatchNorm statistics, momentum buffers, learning-rate schedule and step."""
+        ck = checkpoint.read(path)
+        lrn = cls(checkpoint.config_from(ck), device=device, state_dict=ck["model_state_dict"], loss_impl=loss_impl)
+        if ck.get("optimizer_state_dict") is not None:
+            lrn.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        if ck.get("scheduler_state_dict") is not None:
+            lrn.scheduler.load_state_dict(ck["scheduler_state_dict"])
+        lrn.training_step = int(ck.get("training_step", 0))
+        return lrn
 
     def compute_losses(self, batch, weights):
         """The reference's signature (train.py:330-333): ``batch`` is a list of (stacked uint8

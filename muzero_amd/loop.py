@@ -1,0 +1,86 @@
+"""Self-play feeding training feeding self-play: the pieces of the reference's outer loop
+(train.py:181-206) that touch the search path, for B concurrent games on one GPU.
+
+    play_moves      the loop body train.py:227-282 for all games at once: search, record the
+                    search statistics (Game.store_search_stats), choose, step, record the
+                    transition (Game.store_transition)
+    train_steps     train.py:295-319 on positions sampled from the replay buffer
+    publish         hand the fresh weights to every rank's search engine (one broadcast)
+"""
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import dist as mzdist
+from .learner import GameHistory, Learner, ReplayBuffer, compute_priorities
+from .selfplay import SelfPlayWorker
+
+
+def new_games(worker: SelfPlayWorker, first_frames: torch.Tensor) -> List[GameHistory]:
+    """Reset the frame rings and open one episode record per game (train.py:214-222)."""
+    worker.reset(first_frames)
+    host = first_frames.cpu().numpy()
+    games = [GameHistory(worker.A, worker.config.discount, worker.ring.depth) for _ in range(worker.B)]
+    for g, f in zip(games, host):
+        g.store_transition(None, f, 0)
+    return games
+
+
+def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Callable, moves: int,
+               temperature: float = 1.0) -> None:
+    """``env_step(actions int array [B]) -> (frames uint8 [B,H,W,3] tensor, rewards [B])``.
+    The phase ends by truncation after ``moves`` moves: as in the reference, the step that ends
+    an episode is not recorded (train.py:280-282), so every recorded position has search
+    statistics."""
+    frames = None
+    for move in range(moves):
+        worker.draw_randomness()
+        actions, res = worker.step(frames, temperature)
+        counts = res.visit_counts.cpu().numpy()
+        values = res.root_values.cpu().numpy()
+        acts = actions.cpu().numpy()
+        probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
+        frames, rewards = env_step(acts)
+        host_frames = frames.cpu().numpy()
+        for i, g in enumerate(games):
+            g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
+            g.policies.append(probs[i].astype(np.float64))
+            if move + 1 < moves:
+                g.store_transition(int(acts[i]), host_frames[i], float(rewards[i]))
+    for g in games:
+        g.done = True
+
+
+def save_games(replay: ReplayBuffer, games: List[GameHistory], td_steps: int) -> None:
+    """train.py:286-289.  A game holds one position more than it holds search values (the last
+    frame was never searched); the buffer keeps one priority per position, so that position
+    takes the game's largest priority."""
+    for g in games:
+        pr = compute_priorities(g, td_steps)
+        full = np.full(len(g.rewards), pr.max() if len(pr) else 1.0)
+        n = min(len(pr), len(full))
+        full[:n] = pr[:n]
+        replay.save_game(g, full)
+
+
+def train_steps(learner: Learner, replay: ReplayBuffer, steps: int) -> List[dict]:
+    cfg = learner.config
+    out = []
+    for _ in range(steps):
+        gi, pos, flat, weights = replay.sample_positions()
+        batch = []
+        for g_idx, p in zip(gi, pos):
+            g = replay.buffer[int(g_idx)]
+            batch.append((g.get_observation(int(p)), g.actions[int(p):int(p) + cfg.num_unroll_steps],
+                          g.make_target(int(p), cfg.num_unroll_steps, cfg.td_steps)))      # model.py:602-606
+        m = learner.update_weights(batch, weights)
+        replay.update_priorities(flat, m["priorities"])
+        out.append(m)
+    return out
+
+
+def publish(learner: Optional[Learner], network, src: int = 0) -> None:
+    """Rank ``src`` holds the learner; every rank's search engine gets its weights."""
+    sd = learner.state_dict() if learner is not None else network.state_dict()
+    network.load_state_dict(mzdist.broadcast_state_dict(sd, src=src))

@@ -13,6 +13,8 @@ compiled from their own source text, located with ``ast``, and executed here aga
   g7_losses.npz    small-config network in training mode, a batch of positions ->
                    value / reward / policy losses, per-sample loss, parameter gradients
   g8_targets.npz   Game.make_target / compute_target_value on random episodes
+  g9_checkpoint.pt a checkpoint written by the reference's save_checkpoint after two SGD steps
+  g9_outputs.npz   eval-mode outputs of that network, and the weights one further step gives
 """
 import ast
 import os
@@ -35,7 +37,7 @@ def reference_definitions():
     src = open(path).read()
     tree = ast.parse(src)
     ns = {"np": np, "torch": torch, "device": torch.device("cpu"), "logging": __import__("logging"),
-          "scalar_to_support_loss": M.scalar_to_support_loss, "Node": M.Node,
+          "scalar_to_support_loss": M.scalar_to_support_loss, "Node": M.Node, "os": os,
           "List": __import__("typing").List, "Tuple": __import__("typing").Tuple,
           "Dict": __import__("typing").Dict, "Optional": __import__("typing").Optional}
     out = {}
@@ -45,7 +47,7 @@ def reference_definitions():
             out["Game"] = ns["Game"]
         if isinstance(node, ast.ClassDef) and node.name == "MuZeroTrainer":
             keep = [f for f in node.body if isinstance(f, ast.FunctionDef)
-                    and f.name in ("compute_losses", "prepare_observation")]
+                    and f.name in ("compute_losses", "prepare_observation", "save_checkpoint")]
             stub = ast.ClassDef(name="TrainerStub", bases=[], keywords=[], body=keep, decorator_list=[])
             mod = ast.fix_missing_locations(ast.Module([stub], []))
             exec(compile(mod, path, "exec"), ns)
@@ -88,6 +90,46 @@ def losses_fixture(defs):
                policy_loss=pl.detach().numpy(), per_sample=per.detach().numpy())
     np.savez_compressed(os.path.join(HERE, "g7_losses.npz"), **out)
     print("g7", float(vl), float(rl), float(pl), per.detach().numpy())
+    return stub, batch, weights
+
+
+def checkpoint_fixture(stub, batch, weights):
+    """Two optimiser steps as train.py:303-313 does them, then the reference's save_checkpoint."""
+    import shutil
+    import tempfile
+    cfg, net = stub.config, stub.network
+    net.zero_grad()
+    opt = torch.optim.SGD(net.parameters(), lr=cfg.lr_init, momentum=cfg.momentum, weight_decay=cfg.weight_decay)
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.lr_decay_steps, gamma=cfg.lr_decay_rate)
+
+    def step():
+        _, _, _, per = stub.compute_losses(batch, weights)
+        opt.zero_grad()
+        per.mean().backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.max_grad_norm)
+        opt.step()
+        sch.step()
+        return per.detach().numpy()
+
+    step(); step()
+    stub.optimizer, stub.scheduler, stub.training_step = opt, sch, 2
+    stub.checkpoint_dir = tempfile.mkdtemp()
+    stub.save_checkpoint()
+    shutil.copy(os.path.join(stub.checkpoint_dir, "checkpoint_2.pt"), os.path.join(HERE, "g9_checkpoint.pt"))
+    shutil.rmtree(stub.checkpoint_dir)
+    out = {}
+    net.eval()
+    obs = torch.stack([stub.prepare_observation(o) for o, _, _ in batch])
+    with torch.no_grad():
+        o0 = net.initial_inference(obs)
+        o1 = net.recurrent_inference(o0.hidden_state, torch.tensor([[1], [4], [0], [2]]))
+    out.update(obs=obs.numpy(), h0=o0.hidden_state.numpy(), p0=o0.policy_logits.numpy(), v0=o0.value.numpy(),
+               h1=o1.hidden_state.numpy(), r1=o1.reward.numpy(), p1=o1.policy_logits.numpy(), v1=o1.value.numpy())
+    net.train()
+    out["per_sample_step3"] = step()                      # resumes with the momentum in the checkpoint
+    out.update({f"w3::{k}": v.numpy() for k, v in net.state_dict().items()})
+    np.savez_compressed(os.path.join(HERE, "g9_outputs.npz"), **out)
+    print("g9 ok", out["per_sample_step3"])
 
 
 def targets_fixture(defs):
@@ -127,5 +169,5 @@ def targets_fixture(defs):
 
 if __name__ == "__main__":
     defs = reference_definitions()
-    losses_fixture(defs)
+    checkpoint_fixture(*losses_fixture(defs))
     targets_fixture(defs)

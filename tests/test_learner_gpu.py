@@ -137,3 +137,57 @@ def test_trained_weights_reach_the_search_engine():
     lrn.network.train()
     np.testing.assert_allclose(out.policy_logits.cpu().numpy(), p.cpu().numpy(), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(out.hidden_state.cpu().numpy(), h.cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_reference_checkpoint_feeds_the_search_engine():
+    """A checkpoint written by the reference loads into the inference engine (BatchNorm folded at
+    load); fp32 outputs within 1e-3 of the reference's eval-mode outputs stored beside it."""
+    import os
+    from tests.helpers import GOLDEN
+    from muzero_amd import checkpoint
+    g9 = load("g9_outputs")
+    net = checkpoint.load_network(os.path.join(GOLDEN, "g9_checkpoint.pt"), precision="fp32", input_hw=(32, 32))
+    o0 = net.initial_inference(torch.tensor(g9["obs"]).cuda())
+    o1 = net.recurrent_inference(o0.hidden_state, torch.tensor([[1], [4], [0], [2]]).cuda())
+    for got, key in ((o0.hidden_state, "h0"), (o0.policy_logits, "p0"), (o0.value, "v0"), (o1.hidden_state, "h1"),
+                     (o1.reward, "r1"), (o1.policy_logits, "p1"), (o1.value, "v1")):
+        np.testing.assert_allclose(got.cpu().numpy(), g9[key], rtol=1e-3, atol=2e-4, err_msg=key)
+
+
+def test_selfplay_training_roundtrip():
+    """Search -> episode records -> replay -> update -> weights back into the search engine, at the full
+    network size on a few small games: the loss falls over repeated updates on one replay buffer and the
+    engine's outputs change with the published weights."""
+    from muzero_amd import loop
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.learner import Learner, ReplayBuffer
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg = MuZeroConfig()
+    cfg.observation_shape, cfg.action_space_size, cfg.batch_size = (96, 96, 96), 4, 8
+    cfg.lr_init = 0.01
+    sd = init_state_dict(cfg, seed=0)
+    net = MuZeroNetwork(cfg, precision="bf16", state_dict=sd)
+    learner = Learner(cfg, state_dict=sd)
+    B, moves = 8, 7
+    worker = SelfPlayWorker(cfg, net, B, num_simulations=10)
+    env = SyntheticEnv(B, device="cuda")
+    rng = np.random.default_rng(0)
+    games = loop.new_games(worker, env.reset())
+    loop.play_moves(worker, games, lambda a: (env.step(a), rng.normal(0, 1, B)), moves)
+    for g in games:
+        assert len(g.rewards) == moves and len(g.values) == moves and len(g.policies) == moves
+        assert abs(g.policies[0].sum() - 1) < 1e-12 and g.get_observation(3).shape == (96, 96, 96)
+    replay = ReplayBuffer(cfg)
+    loop.save_games(replay, games, cfg.td_steps)
+    assert len(replay.priorities) == B * moves
+    np.random.seed(0)
+    before = net.initial_inference(worker.obs.permute(0, 3, 1, 2).float()).policy_logits.clone()
+    metrics = loop.train_steps(learner, replay, 6)
+    assert all(np.isfinite(m["total_loss"]) for m in metrics)
+    assert min(m["total_loss"] for m in metrics[3:]) < metrics[0]["total_loss"]
+    loop.publish(learner, net)
+    after = net.initial_inference(worker.obs.permute(0, 3, 1, 2).float()).policy_logits
+    assert not torch.equal(before, after)
+    actions, res = worker.step(None)                       # and the search runs on the new weights
+    assert int(res.visit_counts.sum()) == B * 10
