@@ -254,14 +254,17 @@ int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, 
 int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,
                   mz_stream_t stream);
 
-/* Game.make_target / compute_target_value (train.py:89-118) for n_queries positions:
- * rewards, values double [games][t_max] (padded), n_rewards / n_values int32 [games] their
- * lengths, (q_game, q_pos) int32 [n_queries].  Outputs [n_queries][K+1]: n-step value targets,
- * reward targets (0 past the end) and the index of the stored policy to use (-1 = zeros). */
-int mz_nstep_targets(const double* rewards, const double* values, const int32_t* n_rewards,
-                     const int32_t* n_values, int32_t t_max, const int32_t* q_game, const int32_t* q_pos,
-                     int32_t n_queries, int32_t K, int32_t td_steps, double gamma, double* target_values,
-                     double* target_rewards, int32_t* policy_index, mz_stream_t stream);
+/* Game.make_target / compute_target_value (train.py:89-118) for n_queries positions of a
+ * device-resident episode store.  Episodes lie back to back: game g owns
+ * rewards[reward_off[g] .. reward_off[g+1]) and values / policy rows
+ * [value_off[g] .. value_off[g+1]) (double; policies double [*][A]; offsets int64 [n_games+1]).
+ * (q_game, q_pos) int32 [n_queries].  Outputs double [n_queries][K+1]: n-step value targets,
+ * reward targets (0 past the end) and, when policies / target_policies are given,
+ * [n_queries][K+1][A] policy targets (zeros past the end). */
+int mz_nstep_targets(const double* rewards, const double* values, const double* policies, const int64_t* reward_off,
+                     const int64_t* value_off, int32_t n_games, int32_t A, const int32_t* q_game,
+                     const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
+                     double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream);
 
 #ifdef __cplusplus
 }

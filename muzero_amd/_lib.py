@@ -48,8 +48,8 @@ _SIGNATURES = {
     "mz_nchw_to_nhwc_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_nhwc_to_nchw_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_support_ce": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
-    "mz_nstep_targets": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_double,
-                                   _P, _P, _P, _P]),
+    "mz_nstep_targets": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_double, _P, _P, _P, _P]),
     "mz_ring_push": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
     "mz_ring_to_obs": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -8,11 +8,14 @@
 
 namespace {
 
-// One wavefront per row.  loss = -sum_o t[o] * log_softmax(x)[o] with t the two-hot encoding of
-// the transformed, clamped target; dlogits = softmax(x) * sum(t) - t  (d loss / d x).
+// One wavefront per row, the row held in registers (one pass over HBM in, one out).
+// loss = -sum_o t[o] * log_softmax(x)[o] with t the two-hot encoding of the transformed, clamped
+// target; dlogits = softmax(x) * sum(t) - t  (d loss / d x).
 // The two-hot row is built as the reference's two scatter_ calls do: the upper entry is
 // written after the lower one, so when both indices coincide (target clamped at +S) only
 // prob_upper survives.
+constexpr int kRowRegs = 16;  // 64 lanes x 16 = rows of up to 1024 logits
+
 __global__ __launch_bounds__(256) void support_ce_kernel(const float* __restrict__ logits,
                                                         const float* __restrict__ targets, int n, int S,
                                                         float* __restrict__ loss, float* __restrict__ dlogits) {
@@ -33,12 +36,22 @@ __global__ __launch_bounds__(256) void support_ce_kernel(const float* __restrict
   const float t_lo = lo == up ? p_up : p_lo;  // second scatter overwrites the first
   const float t_sum = lo == up ? p_up : p_lo + p_up;
 
+  float xr[kRowRegs];
   float m = -__builtin_inff();
-  for (int o = lane; o < O; o += 64) m = fmaxf(m, x[o]);
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j) {
+    const int o = lane + 64 * j;
+    xr[j] = o < O ? x[o] : -__builtin_inff();
+    m = fmaxf(m, xr[j]);
+  }
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
   float den = 0.f;
-  for (int o = lane; o < O; o += 64) den += expf(x[o] - m);
+#pragma unroll
+  for (int j = 0; j < kRowRegs; ++j) {
+    xr[j] = expf(xr[j] - m);  // exp(-inf) = 0 past the end of the row
+    den += xr[j];
+  }
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) den += __shfl_xor(den, k);
   const float lse = logf(den);
@@ -49,8 +62,11 @@ __global__ __launch_bounds__(256) void support_ce_kernel(const float* __restrict
   }
   if (dlogits) {
     float* d = dlogits + (long)row * O;
-    for (int o = lane; o < O; o += 64) {
-      float g = expf(x[o] - m) / den * t_sum;
+#pragma unroll
+    for (int j = 0; j < kRowRegs; ++j) {
+      const int o = lane + 64 * j;
+      if (o >= O) break;
+      float g = xr[j] / den * t_sum;
       if (o == lo) g -= t_lo;
       if (o == up && up != lo) g -= p_up;
       d[o] = g;
@@ -58,19 +74,20 @@ __global__ __launch_bounds__(256) void support_ce_kernel(const float* __restrict
   }
 }
 
-// One thread per (query, unroll step).  Episode arrays are padded to t_max.
+// One thread per (query, unroll step).  Episodes are stored back to back: game g owns
+// rewards[r_off[g] .. r_off[g+1]) and values / policy rows [v_off[g] .. v_off[g+1]).
 __global__ void nstep_targets_kernel(const double* __restrict__ rewards, const double* __restrict__ values,
-                                     const int* __restrict__ n_rewards, const int* __restrict__ n_values, int t_max,
-                                     const int* __restrict__ q_game, const int* __restrict__ q_pos, int nq, int K,
-                                     int td, double gamma, double* __restrict__ tv, double* __restrict__ tr,
-                                     int* __restrict__ tp_index) {
+                                     const double* __restrict__ policies, const long* __restrict__ r_off,
+                                     const long* __restrict__ v_off, int A, const int* __restrict__ q_game,
+                                     const int* __restrict__ q_pos, int nq, int K, int td, double gamma,
+                                     double* __restrict__ tv, double* __restrict__ tr, double* __restrict__ tp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq * (K + 1)) return;
   const int q = i / (K + 1), k = i - q * (K + 1);
   const int g = q_game[q], cur = q_pos[q] + k;
-  const double* r = rewards + (long)g * t_max;
-  const double* v = values + (long)g * t_max;
-  const int nr = n_rewards[g], nv = n_values[g];
+  const double* r = rewards + r_off[g];
+  const double* v = values + v_off[g];
+  const int nr = (int)(r_off[g + 1] - r_off[g]), nv = (int)(v_off[g + 1] - v_off[g]);
   double value = 0.0, discount = 1.0;
   for (int j = 0; j < td; ++j) {  // train.py:92-98
     const int idx = cur + j;
@@ -81,7 +98,11 @@ __global__ void nstep_targets_kernel(const double* __restrict__ rewards, const d
   if (cur + td < nv) value += v[cur + td] * discount;  // train.py:99-100
   tv[i] = value;
   tr[i] = cur < nr ? r[cur] : 0.0;                     // train.py:111-116
-  tp_index[i] = cur < nr ? cur : -1;
+  if (tp) {
+    const bool has = cur < nr && cur < nv;             // a position past the end has an all-zero policy
+    const double* p = policies + (v_off[g] + cur) * (long)A;
+    for (int a = 0; a < A; ++a) tp[(long)i * A + a] = has ? p[a] : 0.0;
+  }
 }
 
 }  // namespace
@@ -91,23 +112,26 @@ extern "C" {
 int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,
                   mz_stream_t stream) {
   MZ_REQUIRE(logits && targets && loss && n > 0 && S >= 1, "mz_support_ce: bad arguments");
+  MZ_REQUIRE(2 * S + 1 <= 64 * kRowRegs, "mz_support_ce: support_size %d above the supported 511", S);
   hipLaunchKernelGGL(support_ce_kernel, dim3((n + 3) / 4), dim3(256), 0, mz::as_stream(stream), logits, targets, n,
                      S, loss, dlogits);
   return mz::check_launch("mz_support_ce");
 }
 
-int mz_nstep_targets(const double* rewards, const double* values, const int32_t* n_rewards,
-                     const int32_t* n_values, int32_t t_max, const int32_t* q_game, const int32_t* q_pos,
-                     int32_t n_queries, int32_t K, int32_t td_steps, double gamma, double* target_values,
-                     double* target_rewards, int32_t* policy_index, mz_stream_t stream) {
-  MZ_REQUIRE(rewards && values && n_rewards && n_values && q_game && q_pos && target_values && target_rewards &&
-                 policy_index,
+int mz_nstep_targets(const double* rewards, const double* values, const double* policies, const int64_t* reward_off,
+                     const int64_t* value_off, int32_t n_games, int32_t A, const int32_t* q_game,
+                     const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
+                     double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream) {
+  MZ_REQUIRE(rewards && values && reward_off && value_off && q_game && q_pos && target_values && target_rewards,
              "mz_nstep_targets: null argument");
-  MZ_REQUIRE(t_max > 0 && n_queries > 0 && K >= 0 && td_steps >= 0, "mz_nstep_targets: bad sizes");
+  MZ_REQUIRE((policies != nullptr) == (target_policies != nullptr),
+             "mz_nstep_targets: policies and target_policies go together");
+  MZ_REQUIRE(n_games > 0 && n_queries > 0 && K >= 0 && td_steps >= 0 && A >= 1, "mz_nstep_targets: bad sizes");
   const int total = n_queries * (K + 1);
   hipLaunchKernelGGL(nstep_targets_kernel, dim3((total + 255) / 256), dim3(256), 0, mz::as_stream(stream), rewards,
-                     values, n_rewards, n_values, t_max, q_game, q_pos, n_queries, K, td_steps, gamma,
-                     target_values, target_rewards, policy_index);
+                     values, policies, reinterpret_cast<const long*>(reward_off),
+                     reinterpret_cast<const long*>(value_off), A, q_game, q_pos, n_queries, K, td_steps, gamma,
+                     target_values, target_rewards, target_policies);
   return mz::check_launch("mz_nstep_targets");
 }
 

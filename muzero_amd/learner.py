@@ -244,38 +244,97 @@ class GameHistory:
         return out
 
 
+class EpisodeStore:
+    """Device-resident rewards, search values and search policies of the episodes in the replay
+    window, stored back to back, so that ``make_target`` for a whole training batch is one
+    kernel launch (``mz_nstep_targets``) with only the (game, position) pairs crossing PCIe.
+    Games are addressed by their index in the window; ``pop_front`` follows the replay
+    buffer's eviction of its oldest game."""
+
+    def __init__(self, action_space_size: int, discount: float, device="cuda", capacity: int = 1 << 16):
+        self.A, self.discount, self.device = action_space_size, float(discount), torch.device(device)
+        self.rewards = torch.empty(capacity, dtype=torch.float64, device=self.device)
+        self.values = torch.empty(capacity, dtype=torch.float64, device=self.device)
+        self.policies = torch.empty(capacity, self.A, dtype=torch.float64, device=self.device)
+        self.r_off: List[int] = [0]          # host copies of the offsets; the device copy is refreshed lazily
+        self.v_off: List[int] = [0]
+        self.base = 0                        # games [0, base) have been evicted
+        self._dev_off = None
+
+    def __len__(self):
+        return len(self.r_off) - 1 - self.base
+
+    @staticmethod
+    def _grow(t: torch.Tensor, need: int) -> torch.Tensor:
+        if need <= t.shape[0]:
+            return t
+        new = torch.empty((max(need, 2 * t.shape[0]),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        new[:t.shape[0]] = t
+        return new
+
+    def add_game(self, game: GameHistory) -> int:
+        nr, nv = len(game.rewards), len(game.values)
+        if len(game.policies) != nv:
+            raise ValueError("an episode holds one search policy per search value")
+        r0, v0 = self.r_off[-1], self.v_off[-1]
+        self.rewards = self._grow(self.rewards, r0 + nr)
+        self.values = self._grow(self.values, v0 + nv)
+        self.policies = self._grow(self.policies, v0 + nv)
+        if nr:
+            self.rewards[r0:r0 + nr] = torch.from_numpy(np.asarray(game.rewards, np.float64)).to(self.device)
+        if nv:
+            self.values[v0:v0 + nv] = torch.from_numpy(np.asarray(game.values, np.float64)).to(self.device)
+            self.policies[v0:v0 + nv] = torch.from_numpy(np.asarray(game.policies, np.float64)).to(self.device)
+        self.r_off.append(r0 + nr)
+        self.v_off.append(v0 + nv)
+        self._dev_off = None
+        return len(self) - 1
+
+    def pop_front(self) -> None:
+        self.base += 1
+        if self.base > 1024 and self.base > (len(self.r_off) - 1) // 2:     # compact: drop the evicted prefix
+            r0, v0 = self.r_off[self.base], self.v_off[self.base]
+            self.rewards = self.rewards[r0:].clone()
+            self.values = self.values[v0:].clone()
+            self.policies = self.policies[v0:].clone()
+            self.r_off = [x - r0 for x in self.r_off[self.base:]]
+            self.v_off = [x - v0 for x in self.v_off[self.base:]]
+            self.base = 0
+        self._dev_off = None
+
+    def targets(self, q_game, q_pos, K: int, td_steps: int):
+        """-> float64 device tensors target_values [n, K+1], target_rewards [n, K+1],
+        target_policies [n, K+1, A] (train.py:103-118 for every query)."""
+        if self._dev_off is None:
+            self._dev_off = (torch.tensor(self.r_off, dtype=torch.int64, device=self.device),
+                             torch.tensor(self.v_off, dtype=torch.int64, device=self.device))
+        qg = np.asarray(q_game, np.int64) + self.base
+        qp = np.asarray(q_pos, np.int64)
+        n = qg.shape[0]
+        if n == 0 or qg.min() < self.base or qg.max() >= len(self.r_off) - 1 or qp.min() < 0:
+            raise IndexError("target query outside the stored episodes")
+        d_g = torch.from_numpy(qg.astype(np.int32)).to(self.device)
+        d_p = torch.from_numpy(qp.astype(np.int32)).to(self.device)
+        tv = torch.empty(n, K + 1, dtype=torch.float64, device=self.device)
+        tr = torch.empty(n, K + 1, dtype=torch.float64, device=self.device)
+        tp = torch.empty(n, K + 1, self.A, dtype=torch.float64, device=self.device)
+        _lib.call("mz_nstep_targets", _lib.ptr(self.rewards), _lib.ptr(self.values), _lib.ptr(self.policies),
+                  _lib.ptr(self._dev_off[0]), _lib.ptr(self._dev_off[1]), len(self.r_off) - 1, self.A, _lib.ptr(d_g),
+                  _lib.ptr(d_p), n, K, td_steps, self.discount, _lib.ptr(tv), _lib.ptr(tr), _lib.ptr(tp),
+                  _lib.current_stream())
+        return tv, tr, tp
+
+
 def batched_targets(games: Sequence[GameHistory], queries: Sequence[Tuple[int, int]], K: int, td_steps: int,
                     device="cuda"):
-    """make_target for many (game, position) pairs in one HIP launch.  Returns float64 tensors
-    target_values [n, K+1], target_rewards [n, K+1] and float64 target_policies [n, K+1, A]."""
-    G = len(games)
-    t_max = max(max(len(g.rewards), len(g.values)) for g in games)
-    rew = np.zeros((G, t_max)); val = np.zeros((G, t_max))
-    nr = np.zeros(G, np.int32); nv = np.zeros(G, np.int32)
-    for i, g in enumerate(games):
-        nr[i], nv[i] = len(g.rewards), len(g.values)
-        rew[i, :nr[i]] = g.rewards
-        val[i, :nv[i]] = g.values
-    q = np.asarray(queries, np.int32).reshape(-1, 2)
-    n = q.shape[0]
-    dev = torch.device(device)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_rew, d_val, d_nr, d_nv, d_g, d_p = t(rew), t(val), t(nr), t(nv), t(q[:, 0].copy()), t(q[:, 1].copy())
-    tv = torch.empty(n, K + 1, dtype=torch.float64, device=dev)
-    tr = torch.empty(n, K + 1, dtype=torch.float64, device=dev)
-    pi = torch.empty(n, K + 1, dtype=torch.int32, device=dev)
-    _lib.call("mz_nstep_targets", _lib.ptr(d_rew), _lib.ptr(d_val), _lib.ptr(d_nr), _lib.ptr(d_nv), t_max,
-              _lib.ptr(d_g), _lib.ptr(d_p), n, K, td_steps, float(games[0].discount), _lib.ptr(tv), _lib.ptr(tr),
-              _lib.ptr(pi), _lib.current_stream())
-    A = games[0].action_space_size
-    idx = pi.cpu().numpy()
-    pol = np.zeros((n, K + 1, A))
-    for i in range(n):
-        g = games[q[i, 0]]
-        for k in range(K + 1):
-            if idx[i, k] >= 0:
-                pol[i, k] = g.policies[idx[i, k]]
-    return tv, tr, torch.from_numpy(pol).to(dev)
+    """make_target for many (game, position) pairs of a list of episodes: builds a one-off
+    ``EpisodeStore``.  A replay buffer keeps one instead (``ReplayBuffer(config, store)``)."""
+    store = EpisodeStore(games[0].action_space_size, games[0].discount, device,
+                         capacity=max(1, sum(max(len(g.rewards), len(g.values)) for g in games)))
+    for g in games:
+        store.add_game(g)
+    q = np.asarray(queries, np.int64).reshape(-1, 2)
+    return store.targets(q[:, 0], q[:, 1], K, td_steps)
 
 
 class ReplayBuffer:
@@ -285,13 +344,14 @@ class ReplayBuffer:
     the index after it was reduced to an in-game offset, model.py:595 / :607, and so updates
     the wrong slots)."""
 
-    def __init__(self, config):
+    def __init__(self, config, episode_store: Optional[EpisodeStore] = None):
         self.window_size = config.replay_buffer_size
         self.batch_size = config.batch_size
         self.alpha = config.priority_alpha
         self.beta = config.priority_beta
         self.buffer: List[GameHistory] = []
         self.priorities: List[float] = []
+        self.store = episode_store           # device mirror for batched targets (optional)
 
     def __len__(self):
         return len(self.buffer)
@@ -304,9 +364,13 @@ class ReplayBuffer:
                              "keeps exactly one per position (sampling maps flat indices through game lengths)")
         self.buffer.append(game)
         self.priorities.extend(priorities)
+        if self.store is not None:
+            self.store.add_game(game)
         while len(self.buffer) > self.window_size:
             old = self.buffer.pop(0)
             self.priorities = self.priorities[len(old.rewards):]
+            if self.store is not None:
+                self.store.pop_front()
 
     def sample_positions(self, uniforms: Optional[np.ndarray] = None):
         """-> (game index, in-game position, flat index) arrays and importance weights.
@@ -433,7 +497,14 @@ class Learner:
     def update_weights(self, batch, weights):
         """One optimisation step (train.py:303-313).  Returns the metrics and the per-sample
         losses that become the new replay priorities (train.py:318-319)."""
-        v, r, p, per = self.compute_losses(batch, weights)
+        return self._step(*self.compute_losses(batch, weights))
+
+    def update_from_tensors(self, observations, actions, target_values, target_rewards, target_policies, weights):
+        """``update_weights`` for a batch already in tensor form (see ``losses_from_tensors``)."""
+        return self._step(*self.losses_from_tensors(observations, actions, target_values, target_rewards,
+                                                    target_policies, weights))
+
+    def _step(self, v, r, p, per):
         loss = per.mean()
         self.optimizer.zero_grad()
         loss.backward()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import dist as mzdist
-from .learner import GameHistory, Learner, ReplayBuffer, compute_priorities
+from .learner import GameHistory, Learner, ReplayBuffer, compute_priorities, unroll_actions
 from .selfplay import SelfPlayWorker
 
 
@@ -65,16 +65,24 @@ def save_games(replay: ReplayBuffer, games: List[GameHistory], td_steps: int) ->
 
 
 def train_steps(learner: Learner, replay: ReplayBuffer, steps: int) -> List[dict]:
+    """train.py:295-319.  With a device episode store behind the replay buffer the targets of
+    the whole batch come from one kernel launch; otherwise from ``make_target`` per position."""
     cfg = learner.config
+    K = cfg.num_unroll_steps
     out = []
     for _ in range(steps):
         gi, pos, flat, weights = replay.sample_positions()
-        batch = []
-        for g_idx, p in zip(gi, pos):
-            g = replay.buffer[int(g_idx)]
-            batch.append((g.get_observation(int(p)), g.actions[int(p):int(p) + cfg.num_unroll_steps],
-                          g.make_target(int(p), cfg.num_unroll_steps, cfg.td_steps)))      # model.py:602-606
-        m = learner.update_weights(batch, weights)
+        games = [replay.buffer[int(g)] for g in gi]
+        if replay.store is not None:
+            tv, tr, tp = replay.store.targets(gi, pos, K, cfg.td_steps)
+            obs = torch.from_numpy(np.stack([g.get_observation(int(p)) for g, p in zip(games, pos)]))
+            obs = obs.to(learner.device).permute(0, 3, 1, 2).float() / 255.0
+            acts = unroll_actions([g.actions[int(p):int(p) + K] for g, p in zip(games, pos)], K)    # model.py:604
+            m = learner.update_from_tensors(obs, acts, tv, tr, tp, weights)
+        else:
+            batch = [(g.get_observation(int(p)), g.actions[int(p):int(p) + K], g.make_target(int(p), K, cfg.td_steps))
+                     for g, p in zip(games, pos)]                                                  # model.py:602-606
+            m = learner.update_weights(batch, weights)
         replay.update_priorities(flat, m["priorities"])
         out.append(m)
     return out

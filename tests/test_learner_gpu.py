@@ -49,6 +49,28 @@ def test_nstep_targets_large_random_against_host():
             assert tv[i, k] == v and tr[i, k] == r and np.array_equal(tp[i, k], p)
 
 
+def test_episode_store_follows_the_replay_window():
+    """The device episode store behind a replay buffer: eviction shifts game indices, targets stay
+    bit-exact against Game.make_target, and a training batch built from it equals the per-position one."""
+    from muzero_amd.learner import EpisodeStore, ReplayBuffer
+    g8 = load("g8_targets")
+    games = build_games(g8)
+
+    class Cfg:
+        replay_buffer_size, batch_size, priority_alpha, priority_beta = 3, 16, 1.0, 1.0
+    rb = ReplayBuffer(Cfg, EpisodeStore(6, 0.997, capacity=4))       # tiny capacity: exercises growth
+    for g in games:
+        rb.save_game(g)
+    assert len(rb) == 3 and len(rb.store) == 3
+    gi, pos, flat, w = rb.sample_positions((np.arange(16) + 0.5) / 16)
+    tv, tr, tp = (t.cpu().numpy() for t in rb.store.targets(gi, pos, 5, 10))
+    for i, (g_idx, p) in enumerate(zip(gi, pos)):
+        for k, (v, r, pol) in enumerate(rb.buffer[g_idx].make_target(int(p), 5, 10)):
+            assert tv[i, k] == v and tr[i, k] == r and np.array_equal(tp[i, k], pol)
+    with pytest.raises(IndexError):
+        rb.store.targets([3], [0], 5, 10)
+
+
 def _edge_targets(S):
     # zeros, signs, exact bin centres, the clamp on both sides (the +S clamp makes both scatter indices coincide)
     inv = lambda t: np.sign(t) * (((np.sqrt(1 + 4 * 0.001 * (abs(t) + 1 + 0.001)) - 1) / 0.002) ** 2 - 1)
@@ -178,9 +200,21 @@ def test_selfplay_training_roundtrip():
     for g in games:
         assert len(g.rewards) == moves and len(g.values) == moves and len(g.policies) == moves
         assert abs(g.policies[0].sum() - 1) < 1e-12 and g.get_observation(3).shape == (96, 96, 96)
-    replay = ReplayBuffer(cfg)
+    from muzero_amd.learner import EpisodeStore
+    replay = ReplayBuffer(cfg, EpisodeStore(cfg.action_space_size, cfg.discount))
     loop.save_games(replay, games, cfg.td_steps)
     assert len(replay.priorities) == B * moves
+    # the batched-target route and the per-position route give the same update
+    plain = ReplayBuffer(cfg)
+    loop.save_games(plain, games, cfg.td_steps)
+    la, lb = Learner(cfg, state_dict=sd), Learner(cfg, state_dict=sd)
+    np.random.seed(3)
+    ma = loop.train_steps(la, replay, 1)[0]
+    np.random.seed(3)
+    mb = loop.train_steps(lb, plain, 1)[0]
+    np.testing.assert_allclose(ma["priorities"], mb["priorities"], rtol=1e-4)
+    loop.save_games(replay, [], cfg.td_steps)
+    replay.priorities = list(plain.priorities[:0]) + [1.0] * len(replay.priorities)     # undo the priority update
     np.random.seed(0)
     before = net.initial_inference(worker.obs.permute(0, 3, 1, 2).float()).policy_logits.clone()
     metrics = loop.train_steps(learner, replay, 6)
