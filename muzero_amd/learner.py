@@ -414,8 +414,15 @@ def unroll_actions(action_lists, K: int) -> np.ndarray:
 
 
 class Learner:
-    def __init__(self, config, device="cuda", state_dict=None, loss_impl: Optional[str] = None):
+    def __init__(self, config, device="cuda", state_dict=None, loss_impl: Optional[str] = None,
+                 precision: str = "fp32"):
+        """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
+        convolutions and linear layers under bfloat16 autocast with float32 master weights,
+        BatchNorm statistics and losses."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         self.config = config
+        self.precision = precision
         self.device = torch.device(device)
         self.loss_impl = loss_impl or ("hip" if self.device.type == "cuda" else "torch")
         self.network = TrainableNetwork(config).to(self.device)      # stays in training mode (train.py:155)
@@ -473,7 +480,10 @@ class Learner:
         f32 = lambda x: torch.as_tensor(x, device=dev).float()
         tv, tr, tp, w = f32(target_values), f32(target_rewards), f32(target_policies), f32(weights)
         act = torch.as_tensor(actions, device=dev).long()
-        hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
+        amp = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=self.precision == "bf16")
+        with amp:
+            hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
+        policy_logits, value_logits = policy_logits.float(), value_logits.float()
         reward_logits = None
         total_v = total_r = total_p = 0.0
         per_sample = 0.0
@@ -485,7 +495,10 @@ class Learner:
             total = cfg.value_loss_weight * v_loss + cfg.reward_loss_weight * r_loss + cfg.policy_loss_weight * p_loss
             per_sample = per_sample + total * w
             if t < K:
-                hidden, reward_logits, policy_logits, value_logits = self.network.recurrent(hidden, act[:, t])
+                with amp:
+                    hidden, reward_logits, policy_logits, value_logits = self.network.recurrent(hidden, act[:, t])
+                reward_logits, policy_logits, value_logits = (reward_logits.float(), policy_logits.float(),
+                                                              value_logits.float())
             total_v = total_v + v_loss.mean()
             total_r = total_r + r_loss.mean()
             total_p = total_p + p_loss.mean()

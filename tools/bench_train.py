@@ -40,6 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--rows", type=int, default=1024 * 6, help="loss rows: batch 1024 x (K+1) unroll steps")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -93,32 +94,29 @@ def main():
     # a whole update at the full network size (fp32 torch autograd convolutions + the HIP loss)
     cfg = MuZeroConfig()
     cfg.observation_shape, cfg.action_space_size = (96, 96, 96), 18
-    lrn = Learner(cfg, device=dev, state_dict=init_state_dict(cfg, seed=0))
     B, K, A = args.batch, cfg.num_unroll_steps, cfg.action_space_size
     obs = torch.rand(B, 96, 96, 96, device=dev)
     acts = rng.integers(0, A, (B, K))
     tv, tr = rng.normal(0, 5, (B, K + 1)), rng.normal(0, 1, (B, K + 1))
     tp = rng.dirichlet(np.ones(A), (B, K + 1))
     w = np.ones(B)
-
-    def update():
-        _, _, _, per = lrn.losses_from_tensors(obs, acts, tv, tr, tp, w)
-        lrn.optimizer.zero_grad()
-        per.mean().backward()
-        torch.nn.utils.clip_grad_norm_(lrn.network.parameters(), cfg.max_grad_norm)
-        lrn.optimizer.step()
-    for _ in range(2):
-        update()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        update()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    # forward FLOPs per position: representation + K recurrent steps; backward ~2x forward
-    fwd = 5_181_014_016 + K * 850_364_416
-    out["update_weights"] = {"batch": B, "unroll": K, "ms_per_step": dt * 1e3, "positions_per_s": B / dt,
-                             "model_TFLOP/s": 3 * fwd * B / dt / 1e12, "dtype": "f32"}
+    fwd = 5_181_014_016 + K * 850_364_416      # forward FLOPs per position; backward ~2x forward
+    for precision in ("fp32", "bf16"):
+        lrn = Learner(cfg, device=dev, state_dict=init_state_dict(cfg, seed=0), precision=precision)
+        if args.channels_last:
+            lrn.network.to(memory_format=torch.channels_last)
+        for _ in range(2):
+            lrn.update_from_tensors(obs, acts, tv, tr, tp, w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            m = lrn.update_from_tensors(obs, acts, tv, tr, tp, w)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        out["update_weights_" + precision] = {"batch": B, "unroll": K, "ms_per_step": dt * 1e3,
+                                              "positions_per_s": B / dt, "model_TFLOP/s": 3 * fwd * B / dt / 1e12,
+                                              "loss": m["total_loss"]}
+        del lrn
     print(json.dumps(out))
 
 
