@@ -180,6 +180,7 @@ def main():
     assert actions.shape == (B,)
     elapsed = mzdist.max_over_ranks(elapsed)
     visits_ok = int(worker.mcts.visits.sum().item()) == B * args.sims
+    worker.mcts.check_status()
 
     if rank == 0:
         total_sims = world * B * args.sims * args.steps

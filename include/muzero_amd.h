@@ -29,6 +29,7 @@ typedef void* mz_stream_t; /* a hipStream_t; NULL = the default stream */
 #define MZ_E_STATE -3   /* object used in the wrong state */
 
 #define MZ_MAX_ACTIONS 64  /* one wavefront lane per action */
+#define MZ_MAX_NODES 1024  /* expanded nodes per tree: the backup stages two doubles per node per wavefront in LDS */
 
 int mz_version(void);
 const char* mz_last_error(void);
@@ -64,10 +65,10 @@ typedef struct mz_tree_layout {
   int64_t path_len;     /* int32  [B] */
   int64_t leaf_parent;  /* int32  [B] node whose edge leaf_action is unexpanded */
   int64_t leaf_action;  /* int32  [B] */
-  int64_t status;       /* int32  [B] 0 ok, 1 no selectable child, 2 tree full */
+  int64_t status;       /* int32  [B] 0 ok, 1 no selectable child, 2 tree full, 3 score tables shorter than a visit count */
 } mz_tree_layout;
 
-/* Host-only: fills *out for (B, A, max_nodes). 1 <= A <= MZ_MAX_ACTIONS. */
+/* Host-only: fills *out for (B, A, max_nodes). 1 <= A <= MZ_MAX_ACTIONS, 2 <= max_nodes <= MZ_MAX_NODES. */
 int mz_tree_layout_query(int32_t B, int32_t A, int32_t max_nodes, mz_tree_layout* out);
 
 /* Root construction for B games: Node(0).expand(...) with reward 0

@@ -89,6 +89,22 @@ def call(name, *args):
         raise MuZeroAmdError(f"{name} failed ({rc}): {msg}")
 
 
+def expect(t, name, dtype=None, shape=None, cuda=True, contiguous=True):
+    """Validate a tensor before its address goes to a kernel; ValueError otherwise (kernels index
+    by the shapes their arguments claim, so a mismatch would be an out-of-bounds access)."""
+    if t is None:
+        raise ValueError(f"{name}: tensor required")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if cuda and not t.is_cuda:
+        raise ValueError(f"{name}: must live on the GPU")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
 def ptr(t):
     """Device (or host) address of a torch tensor, or NULL for None."""
     return None if t is None else C.c_void_p(t.data_ptr())

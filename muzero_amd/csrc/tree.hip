@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double
       n = t.visit[row + lane];
       kid = t.child[row + lane];
       const double w = t.value_sum[row + lane];
-      const int pn = parent_n < table_len ? parent_n : table_len - 1;
+      const int pn = parent_n < table_len ? parent_n : table_len - 1;  // too-short tables are reported below
       const double c = pbc[pn] * (sq[pn] / (double)(n + 1));
       double vs = 0.0;
       if (n > 0) vs = hi > lo ? (w / (double)n - lo) / (hi - lo) : 0.5;
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double
       }
     }
     best_a = wave_uniform(best_a);
+    if (parent_n >= table_len) bad = 3;
     if (!(best > ninf)) {  // the reference would return action -1 / child None here
       bad = 1;
       best_a = 0;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double
         t.leaf_parent[b] = node;
         t.leaf_action[b] = best_a;
         t.path_len[b] = depth;
-        if (bad) t.status[b] = 1;
+        if (bad) t.status[b] = bad;
       }
       break;
     }
@@ -355,7 +356,7 @@ int blocks_for(int B) { return (B + kWavesPerBlock - 1) / kWavesPerBlock; }
 
 int check_tree_args(const void* ws, const mz_tree_layout* L) {
   MZ_REQUIRE(ws != nullptr && L != nullptr, "tree: null workspace or layout");
-  MZ_REQUIRE(L->B > 0 && L->A >= 1 && L->A <= MZ_MAX_ACTIONS && L->max_nodes >= 2,
+  MZ_REQUIRE(L->B > 0 && L->A >= 1 && L->A <= MZ_MAX_ACTIONS && L->max_nodes >= 2 && L->max_nodes <= MZ_MAX_NODES,
              "tree: bad layout (B=%d A=%d max_nodes=%d)", L->B, L->A, L->max_nodes);
   return MZ_OK;
 }
@@ -366,9 +367,9 @@ extern "C" {
 
 int mz_tree_layout_query(int32_t B, int32_t A, int32_t max_nodes, mz_tree_layout* out) {
   MZ_REQUIRE(out != nullptr, "mz_tree_layout_query: out is null");
-  MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && max_nodes >= 2 && max_nodes <= 4096,
-             "mz_tree_layout_query: need B>0, 1<=A<=%d, 2<=max_nodes<=4096 (got %d, %d, %d)",
-             MZ_MAX_ACTIONS, B, A, max_nodes);
+  MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && max_nodes >= 2 && max_nodes <= MZ_MAX_NODES,
+             "mz_tree_layout_query: need B>0, 1<=A<=%d, 2<=max_nodes<=%d (got %d, %d, %d)", MZ_MAX_ACTIONS,
+             MZ_MAX_NODES, B, A, max_nodes);
   mz_tree_layout L{};
   L.B = B; L.A = A; L.max_nodes = max_nodes;
   int64_t off = 0;

@@ -49,7 +49,7 @@ class NetworkOutput:
 
 def support_to_scalar(logits: torch.Tensor, support_size: int) -> torch.Tensor:
     """model.py:98-109 on the device: float32 logits [n, 2S+1] -> float32 [n]."""
-    assert logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] == 2 * support_size + 1
+    _lib.expect(logits, "logits", torch.float32, (logits.shape[0], 2 * support_size + 1), contiguous=False)
     logits = logits.contiguous()
     out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
     _lib.call("mz_support_to_scalar", _lib.ptr(logits), logits.shape[0], support_size, _lib.ptr(out),
@@ -358,13 +358,16 @@ class MuZeroNetwork:
     def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
         """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W]."""
         B, H, W, _ = obs_nhwc.shape
+        hh, hw = self.hidden_hw(H, W)
+        _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, H, W, self.cin))
+        _lib.expect(hidden_out, "hidden_out", self.act_dtype, (B, hh, hw, self.W))
+        _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
         x = obs_nhwc
         plan = self.rep_plan
         # the trailing residual blocks at the hidden resolution run as one fused chain
         n_tail = 0
         while n_tail < len(plan) and plan[len(plan) - 1 - n_tail][0] == "res":
             n_tail += 1
-        hh, hw = self.hidden_hw(H, W)
         tail = [item for _, item in plan[len(plan) - n_tail:]]
         fuse = n_tail > 0 and self._chain_ok([c for blk in tail for c in blk], hh, hw)
         head = plan[:len(plan) - n_tail] if fuse else plan
@@ -389,6 +392,16 @@ class MuZeroNetwork:
                  actions: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
         """hidden' = dynamics(pool[in_slot[b]*slot_stride + b], actions[b]) for every b."""
         B, H, W, c = hidden_out.shape
+        _lib.expect(hidden_out, "hidden_out", self.act_dtype, (B, H, W, self.W))
+        _lib.expect(actions, "actions", torch.int32, (B,))
+        _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
+        if in_slot is None:
+            _lib.expect(pool, "hidden_state", self.act_dtype, (B, H, W, self.W))
+        else:
+            _lib.expect(in_slot, "in_slot", torch.int32, (B,))
+            _lib.expect(pool, "pool", self.act_dtype)
+            if pool.dim() != 5 or tuple(pool.shape[1:]) != (B, H, W, self.W) or slot_stride != B:
+                raise ValueError(f"pool must be [slots, {B}, {H}, {W}, {self.W}] with slot_stride {B}")
         if self._chain_ok([self.dyn_first] + [l for blk in self.dyn_blocks for l in blk], H, W):
             timing = self.dynamics_events  # optional list: (start, end) event pairs around each launch
             if timing is not None:
@@ -458,6 +471,8 @@ class MuZeroNetwork:
         hs = self._to_nhwc(hidden_state.to(self.device))
         B, h, w, _ = hs.shape
         actions = action.to(self.device).view(B).to(torch.int32).contiguous()
+        if B and (int(actions.min()) < 0 or int(actions.max()) >= self.A):    # the kernel gathers by action
+            raise IndexError(f"action outside [0, {self.A})")
         out = torch.empty(B, h, w, self.W, dtype=self.act_dtype, device=self.device)
         mean = self._buf("mean", (B, self.W), torch.float32)
         self.dynamics(hs, None, 0, actions, out, mean)

@@ -25,7 +25,7 @@ class FrameRing:
         self.newest = depth - 1
 
     def _stage(self, frames: torch.Tensor) -> torch.Tensor:
-        assert frames.dtype == torch.uint8 and tuple(frames.shape) == (self.B, self.H, self.W, 3)
+        _lib.expect(frames, "frames", torch.uint8, (self.B, self.H, self.W, 3), cuda=False, contiguous=False)
         if frames.is_cuda:
             return frames.contiguous()
         self.staging.copy_(frames, non_blocking=True)
@@ -45,9 +45,11 @@ class FrameRing:
 
     def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None) -> torch.Tensor:
         """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255."""
-        assert dtype in (torch.bfloat16, torch.float32)
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("observation dtype must be bfloat16 or float32")
         if out is None:
             out = torch.empty(self.B, self.H, self.W, 3 * self.depth, dtype=dtype, device=self.device)
+        _lib.expect(out, "out", dtype, (self.B, self.H, self.W, 3 * self.depth))
         _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
                   self.B, self.depth, self.H * self.W, self.newest, _lib.current_stream())
         return out
@@ -57,7 +59,7 @@ def prepare_observation(observation: torch.Tensor) -> torch.Tensor:
     """train.py:529-540 on the device: uint8 HWC or NHWC -> float32 CHW or NCHW, x / 255."""
     single = observation.dim() == 3
     x = observation.unsqueeze(0) if single else observation
-    assert x.dtype == torch.uint8
+    _lib.expect(x, "observation", torch.uint8, cuda=False, contiguous=False)
     x = x.cuda().contiguous()
     B, H, W, Cc = x.shape
     out = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)

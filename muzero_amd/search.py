@@ -103,6 +103,16 @@ class BatchedMCTS:
         self._search(observations, noise)
         return SearchResult(self.visits, self.root_values, self.probs)
 
+    def check_status(self) -> None:
+        """Raise if any tree reported trouble during the last search (one device read-back;
+        call it outside timed or captured regions)."""
+        st = self.trees.array("status")
+        if bool((st != 0).any()):
+            codes = {1: "no selectable child", 2: "tree full", 3: "score tables shorter than a visit count"}
+            bad = int((st != 0).nonzero()[0].item())
+            code = int(st[bad].item())
+            raise _lib.MuZeroAmdError(f"search: game {bad} reported status {code} ({codes.get(code, '?')})")
+
     def capture(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None):
         """Record one whole search (initial inference, every simulation step, read-out)
         into a HIP graph reading ``observations`` / ``noise`` in place.  Returns a

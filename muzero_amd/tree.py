@@ -57,9 +57,9 @@ class DeviceTrees:
         return self.ws[off:off + nbytes].view(dt).view(*shape)
 
     def root_init(self, priors: torch.Tensor, noise: torch.Tensor = None, frac: float = 0.25):
-        assert priors.dtype == torch.float32 and priors.is_contiguous() and priors.shape == (self.B, self.A)
+        _lib.expect(priors, "priors", torch.float32, (self.B, self.A))
         if noise is not None:
-            assert noise.dtype == torch.float64 and noise.is_contiguous() and noise.shape == (self.B, self.A)
+            _lib.expect(noise, "noise", torch.float64, (self.B, self.A))
         keep = float(np.float32(1.0 - frac))  # the float32 factor of prior * (1 - frac)
         _lib.call("mz_tree_root_init", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(priors),
                   _lib.ptr(noise), keep, float(frac), _lib.current_stream())
@@ -69,8 +69,9 @@ class DeviceTrees:
                   _lib.ptr(self.sq), self.table_len, _lib.current_stream())
 
     def expand_backup(self, priors, value, reward, wave: int = 1, gamma: float = 0.997):
-        for t, shp in ((priors, (self.B, self.A)), (value, (self.B,)), (reward, (self.B,))):
-            assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shp, (t.shape, shp)
+        _lib.expect(priors, "priors", torch.float32, (self.B, self.A))
+        _lib.expect(value, "value", torch.float32, (self.B,))
+        _lib.expect(reward, "reward", torch.float32, (self.B,))
         _lib.call("mz_tree_expand_backup", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(priors),
                   _lib.ptr(value), _lib.ptr(reward), int(wave), float(gamma), _lib.current_stream())
 
@@ -81,6 +82,9 @@ class DeviceTrees:
             root_value = torch.empty(self.B, dtype=torch.float64, device=self.device)
         if probs is None:
             probs = torch.empty(self.B, self.A, dtype=torch.float64, device=self.device)
+        _lib.expect(visits, "visits", torch.int32, (self.B, self.A))
+        _lib.expect(root_value, "root_value", torch.float64, (self.B,))
+        _lib.expect(probs, "probs", torch.float64, (self.B, self.A))
         _lib.call("mz_tree_readout", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(visits),
                   _lib.ptr(root_value), _lib.ptr(probs), _lib.current_stream())
         return visits, root_value, probs
@@ -89,9 +93,9 @@ class DeviceTrees:
 def select_actions(visits: torch.Tensor, temperature: float, u: torch.Tensor = None) -> torch.Tensor:
     """Device select_action (model.py:530-546) for every row of ``visits``."""
     B, A = visits.shape
-    assert visits.dtype == torch.int32 and visits.is_contiguous()
+    _lib.expect(visits, "visits", torch.int32)
     if temperature != 0:
-        assert u is not None and u.dtype == torch.float64 and u.shape == (B,)
+        _lib.expect(u, "u", torch.float64, (B,))
     out = torch.empty(B, dtype=torch.int32, device=visits.device)
     _lib.call("mz_select_action", _lib.ptr(visits), B, A, float(temperature), _lib.ptr(u), _lib.ptr(out),
               _lib.current_stream())
