@@ -105,6 +105,13 @@ int mz_tree_expand_backup(void* ws, const mz_tree_layout* L, const float* priors
                           const float* value, const float* reward, int32_t wave,
                           double gamma, mz_stream_t stream);
 
+/* mz_tree_expand_backup for simulation s followed by mz_tree_select for simulation s + 1 in
+ * one launch (both work wavefront-per-game on the same game, so no grid-wide ordering is
+ * needed).  Same results as the two calls in sequence; saves a launch per simulation. */
+int mz_tree_expand_backup_select(void* ws, const mz_tree_layout* L, const float* priors, const float* value,
+                                 const float* reward, int32_t wave, double gamma, const double* pbc_table,
+                                 const double* sqrt_table, int32_t table_len, mz_stream_t stream);
+
 /* Search result per game (model.py:472-480 and Node.value, model.py:386-389):
  * visits int32 [B][A], root_value double [B], probs double [B][A]
  * (uniform when no child was visited). Any output may be NULL. */
@@ -133,7 +140,9 @@ int mz_select_action(const int32_t* visits, int32_t B, int32_t A, double tempera
  * the per-game node pool, replacing torch.cat at model.py:452).
  * action_vec (optional, float [n_actions][Cin]) with actions int32 [B]:
  * x = in + action_vec[actions[b]] inside the image before the convolution,
- * which equals hidden + conv_action(one_hot planes) (model.py:231-236). */
+ * which equals hidden + conv_action(one_hot planes) (model.py:231-236).
+ * Preconditions the caller guarantees (device data the host wrapper cannot see):
+ * 0 <= actions[b] < n_actions and in_slot[b] * slot_stride + b inside `in`. */
 int mz_conv3x3_f32(const float* in, const int32_t* in_slot, int32_t slot_stride, const float* w,
                    const float* bias, const float* residual, float* out, const float* action_vec,
                    const int32_t* actions, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmuzero_amd.so")
+# MUZERO_AMD_LIB points at another build of the same library (kernel A/B comparisons)
+LIB_PATH = os.environ.get("MUZERO_AMD_LIB") or os.path.join(_HERE, "csrc", "libmuzero_amd.so")
 
 
 class MuZeroAmdError(RuntimeError):
@@ -35,6 +36,8 @@ _SIGNATURES = {
     "mz_tree_root_init": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, C.c_float, C.c_double, _P]),
     "mz_tree_select": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, C.c_int32, _P]),
     "mz_tree_expand_backup": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P]),
+    "mz_tree_expand_backup_select": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P, _P,
+                                               C.c_int32, _P]),
     "mz_tree_readout": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, _P]),
     "mz_select_action": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
     "mz_conv3x3_f32": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),

@@ -280,10 +280,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
     }
   }
 
+  int touched = 0;  // sink of the next-image prefetch loads (keeps them alive; never stored)
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
     const __bf16* src = a.in + img * (long)(kPix * kCh);
     const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
+    // this workgroup's next image: one 4-byte load per 128-byte line pulls all 72 KB of it towards
+    // L2 while the last layer of the current image computes (every workgroup otherwise fetches its
+    // image from HBM in the same instant, and waits for that burst)
+    const int nb = b + gridDim.x;
+    const char* nsrc = nullptr;
+    if (nb < a.B) {
+      const long nimg = a.in_slot ? (long)a.in_slot[nb] * a.slot_stride + nb : nb;
+      nsrc = reinterpret_cast<const char*>(a.in + nimg * (long)(kPix * kCh));
+    }
 
     // first layer's weights are requested before the image so that both are in flight together
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk[0]) + (long)wave * WN * 64 + lane;
@@ -333,6 +343,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt]);
 
+      int pf0 = 0, pf1 = 0;
+      if (last && nsrc) {  // 576 lines of 128 bytes, 512 threads
+        pf0 = *reinterpret_cast<const int*>(nsrc + tid * 128);
+        if (tid < kPix * kCh * 2 / 128 - 64 * NW) pf1 = *reinterpret_cast<const int*>(nsrc + (64 * NW + tid) * 128);
+      }
+
 #pragma unroll 1
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -373,6 +389,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
         }
       }
 
+      touched ^= pf0 ^ pf1;
       // next layer's first weight fragments travel while this layer's epilogue runs
       const float* bias = a.bias[l];
       const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
@@ -438,6 +455,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
     }
     __syncthreads();  // the next image overwrites buffer 0
   }
+  if (a.B < 0) a.mean_out[tid] = __int_as_float(touched);  // never true: B > 0 is checked by the host
 }
 
 template <int NW, int PF>

@@ -99,11 +99,8 @@ __global__ __launch_bounds__(kBlock) void root_init_kernel(TreeView t, const flo
 }
 
 // ------------------------------------------------------------------ select
-__global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double* __restrict__ pbc,
-                                                       const double* __restrict__ sq, int table_len) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (b >= t.B) return;
+__device__ __forceinline__ void select_game(const TreeView& t, const double* __restrict__ pbc,
+                                            const double* __restrict__ sq, int table_len, int b, int lane) {
   const int A = t.A;
   const double lo = t.minmax[2 * b], hi = t.minmax[2 * b + 1];
   const bool root64 = t.root_is_f64[b] != 0;
@@ -171,26 +168,25 @@ __global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double
   }
 }
 
+__global__ __launch_bounds__(kBlock) void select_kernel(TreeView t, const double* __restrict__ pbc,
+                                                       const double* __restrict__ sq, int table_len) {
+  const int b = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (b < t.B) select_game(t, pbc, sq, table_len, b, threadIdx.x & 63);
+}
+
 // ----------------------------------------------------------- expand + backup
-// Dynamic LDS: per wave two double arrays of max_nodes entries
-// (reward of each node on the path, value added at each node).
-__global__ __launch_bounds__(kBlock) void expand_backup_kernel(TreeView t, const float* __restrict__ priors,
-                                                              const float* __restrict__ value,
-                                                              const float* __restrict__ reward, int wave,
-                                                              double gamma) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int w = threadIdx.x >> 6;
-  const int b = blockIdx.x * kWavesPerBlock + w;
-  if (b >= t.B) return;
-  double* rwd = reinterpret_cast<double*>(smem) + (size_t)w * 2 * t.N;
-  double* val = rwd + t.N;
+// rwd / val: per-wave LDS arrays of max_nodes doubles (reward of each node on the path, value
+// added at each node).  Returns false when the game's tree is full (status 2).
+__device__ __forceinline__ bool expand_backup_game(const TreeView& t, const float* __restrict__ priors,
+                                                   const float* __restrict__ value,
+                                                   const float* __restrict__ reward, int wave, double gamma,
+                                                   double* rwd, double* val, int b, int lane) {
   const int A = t.A;
   const int e = wave_uniform(t.num_nodes[b]);
   const int len = wave_uniform(t.path_len[b]);
   if (e >= t.N || len <= 0) {
     if (lane == 0) t.status[b] = 2;
-    return;
+    return false;
   }
   const int parent = wave_uniform(t.leaf_parent[b]);
   const int act = wave_uniform(t.leaf_action[b]);
@@ -268,6 +264,39 @@ __global__ __launch_bounds__(kBlock) void expand_backup_kernel(TreeView t, const
     t.minmax[2 * b] = lo < plo ? lo : plo;
     t.minmax[2 * b + 1] = hi > phi ? hi : phi;
   }
+  return true;
+}
+
+// Dynamic LDS: per wave two double arrays of max_nodes entries.
+__global__ __launch_bounds__(kBlock) void expand_backup_kernel(TreeView t, const float* __restrict__ priors,
+                                                              const float* __restrict__ value,
+                                                              const float* __restrict__ reward, int wave,
+                                                              double gamma) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = threadIdx.x >> 6;
+  const int b = blockIdx.x * kWavesPerBlock + w;
+  if (b >= t.B) return;
+  double* rwd = reinterpret_cast<double*>(smem) + (size_t)w * 2 * t.N;
+  expand_backup_game(t, priors, value, reward, wave, gamma, rwd, rwd + t.N, b, threadIdx.x & 63);
+}
+
+// expand + backup of simulation s followed by the descent of simulation s + 1 for the same
+// game: both are wavefront-per-game, so the only ordering needed is this wavefront's own
+// stores before its own loads.  A workgroup-scope fence is enough (one compute unit, one
+// write-through L1); a device-scope fence would write back the whole L2 slice per wavefront.
+__global__ __launch_bounds__(kBlock) void expand_backup_select_kernel(TreeView t, const float* __restrict__ priors,
+                                                                     const float* __restrict__ value,
+                                                                     const float* __restrict__ reward, int wave,
+                                                                     double gamma, const double* __restrict__ pbc,
+                                                                     const double* __restrict__ sq, int table_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * kWavesPerBlock + w;
+  if (b >= t.B) return;
+  double* rwd = reinterpret_cast<double*>(smem) + (size_t)w * 2 * t.N;
+  if (!expand_backup_game(t, priors, value, reward, wave, gamma, rwd, rwd + t.N, b, lane)) return;
+  __threadfence_block();
+  select_game(t, pbc, sq, table_len, b, lane);
 }
 
 // ----------------------------------------------------------------- readout
@@ -431,6 +460,20 @@ int mz_tree_expand_backup(void* ws, const mz_tree_layout* L, const float* priors
   hipLaunchKernelGGL(expand_backup_kernel, dim3(blocks_for(L->B)), dim3(kBlock), lds, mz::as_stream(stream),
                      t, priors, value, reward, wave, gamma);
   return mz::check_launch("mz_tree_expand_backup");
+}
+
+int mz_tree_expand_backup_select(void* ws, const mz_tree_layout* L, const float* priors, const float* value,
+                                 const float* reward, int32_t wave, double gamma, const double* pbc_table,
+                                 const double* sqrt_table, int32_t table_len, mz_stream_t stream) {
+  if (int rc = check_tree_args(ws, L)) return rc;
+  MZ_REQUIRE(priors && value && reward, "mz_tree_expand_backup_select: null network output");
+  MZ_REQUIRE(wave >= 1, "mz_tree_expand_backup_select: wave must be >= 1 (got %d)", wave);
+  MZ_REQUIRE(pbc_table && sqrt_table && table_len >= 2, "mz_tree_expand_backup_select: bad score tables");
+  TreeView t = make_view(ws, L);
+  const size_t lds = (size_t)kWavesPerBlock * 2 * L->max_nodes * sizeof(double);
+  hipLaunchKernelGGL(expand_backup_select_kernel, dim3(blocks_for(L->B)), dim3(kBlock), lds, mz::as_stream(stream),
+                     t, priors, value, reward, wave, gamma, pbc_table, sqrt_table, table_len);
+  return mz::check_launch("mz_tree_expand_backup_select");
 }
 
 int mz_tree_readout(const void* ws, const mz_tree_layout* L, int32_t* visits, double* root_value,

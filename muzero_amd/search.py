@@ -82,17 +82,23 @@ class BatchedMCTS:
         self.probs = torch.empty(batch_size, self.A, dtype=torch.float64, device=dev)
         self.leaf_parent = self.trees.array("leaf_parent")
         self.leaf_action = self.trees.array("leaf_action")
+        self.fuse_tree_step = True  # False: separate expand_backup and select launches (same results)
 
     def _search(self, observations: torch.Tensor, noise: Optional[torch.Tensor]) -> None:
         cfg = self.config
         priors, value = self.net.initial_to_pool(observations, self.pool[0])
         self.root_priors, self.root_net_value = priors, value
         self.trees.root_init(priors, noise, cfg.root_exploration_fraction)
+        fuse = self.fuse_tree_step
+        self.trees.select()
         for s in range(self.steps):
-            self.trees.select()
             priors, value, reward = self.net.recurrent_in_pool(self.pool, self.leaf_parent, self.B,
                                                                 self.leaf_action, self.pool[s + 1])
-            self.trees.expand_backup(priors, value, reward, self.wave, cfg.discount)
+            # the descent of the next simulation rides in the same launch as this one's backup
+            step = self.trees.expand_backup_select if fuse and s + 1 < self.steps else self.trees.expand_backup
+            step(priors, value, reward, self.wave, cfg.discount)
+            if not fuse and s + 1 < self.steps:
+                self.trees.select()
         self.trees.readout(self.visits, self.root_values, self.probs)
 
     def run(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None) -> SearchResult:

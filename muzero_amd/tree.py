@@ -75,6 +75,15 @@ class DeviceTrees:
         _lib.call("mz_tree_expand_backup", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(priors),
                   _lib.ptr(value), _lib.ptr(reward), int(wave), float(gamma), _lib.current_stream())
 
+    def expand_backup_select(self, priors, value, reward, wave: int = 1, gamma: float = 0.997):
+        """``expand_backup`` followed by the next ``select`` in one launch."""
+        _lib.expect(priors, "priors", torch.float32, (self.B, self.A))
+        _lib.expect(value, "value", torch.float32, (self.B,))
+        _lib.expect(reward, "reward", torch.float32, (self.B,))
+        _lib.call("mz_tree_expand_backup_select", _lib.ptr(self.ws), C.byref(self.layout), _lib.ptr(priors),
+                  _lib.ptr(value), _lib.ptr(reward), int(wave), float(gamma), _lib.ptr(self.pbc), _lib.ptr(self.sq),
+                  self.table_len, _lib.current_stream())
+
     def readout(self, visits=None, root_value=None, probs=None):
         if visits is None:
             visits = torch.empty(self.B, self.A, dtype=torch.int32, device=self.device)

@@ -9,7 +9,8 @@ from tests.helpers import TREE_CASES, TableNet, child_hash, load
 pytestmark = pytest.mark.gpu
 
 
-def run_device_search(g, root_hash, noise, sims, wave, record_paths=False):
+def run_device_search(g, root_hash, noise, sims, wave, record_paths=False, fused=False):
+    """fused: every descent after the first runs inside the expand+backup launch of the step before."""
     from muzero_amd.tree import DeviceTrees
     A = int(g["A"])
     B = len(root_hash)
@@ -25,8 +26,10 @@ def run_device_search(g, root_hash, noise, sims, wave, record_paths=False):
                     None if noise is None else torch.from_numpy(noise).to(dev), float(g["frac"]))
     paths = []
     ar = np.arange(B)
-    for s in range(sims // wave):
-        trees.select()
+    steps = sims // wave
+    for s in range(steps):
+        if s == 0 or not fused:
+            trees.select()
         parent = trees.array("leaf_parent").cpu().numpy()
         act = trees.array("leaf_action").cpu().numpy()
         if record_paths:
@@ -35,19 +38,21 @@ def run_device_search(g, root_hash, noise, sims, wave, record_paths=False):
         kid = child_hash(node_hash[ar, parent], act.astype(np.int64))
         node_hash[:, s + 1] = kid
         r = kid % rows
-        trees.expand_backup(torch.from_numpy(pri_t[r]).to(dev), torch.from_numpy(val_t[r]).to(dev),
-                            torch.from_numpy(rew_t[r]).to(dev), wave, float(g["gamma"]))
+        step = trees.expand_backup_select if fused and s + 1 < steps else trees.expand_backup
+        step(torch.from_numpy(pri_t[r]).to(dev), torch.from_numpy(val_t[r]).to(dev),
+             torch.from_numpy(rew_t[r]).to(dev), wave, float(g["gamma"]))
     torch.cuda.synchronize()
     assert int(trees.array("status").abs().sum()) == 0
     return trees, paths
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", TREE_CASES)
-def test_tree_kernels_match_reference_fixtures(case):
+def test_tree_kernels_match_reference_fixtures(case, fused):
     g = load("g1_tree_" + case)
     sims, wave = int(g["sims"]), int(g["wave"])
     noise = g["noise"] if int(g["noise_on"]) else None
-    trees, paths = run_device_search(g, g["root_hash"].astype(np.int64), noise, sims, wave, True)
+    trees, paths = run_device_search(g, g["root_hash"].astype(np.int64), noise, sims, wave, True, fused)
     visits, root_value, probs = trees.readout()
     assert np.array_equal(visits.cpu().numpy(), g["visits"])
     assert np.array_equal(root_value.cpu().numpy(), g["root_value"])
@@ -66,8 +71,8 @@ def test_tree_kernels_match_reference_fixtures(case):
                 assert pact[b, :plen[b]].tolist() == g["path_act"][b, s * wave + w, :plen[b]].tolist()
 
 
-@pytest.mark.parametrize("A,B,wave", [(18, 1024, 1), (6, 256, 1), (9, 333, 5)])
-def test_tree_kernels_match_oracle_at_batch_size(A, B, wave):
+@pytest.mark.parametrize("A,B,wave,fused", [(18, 1024, 1, True), (6, 256, 1, False), (9, 333, 5, True)])
+def test_tree_kernels_match_oracle_at_batch_size(A, B, wave, fused):
     from oracle import tree as otree
     case = {18: "a18_w1_noise", 6: "a6_w1_noise", 9: "a9_w1_plain"}[A]
     g = load("g1_tree_" + case)
@@ -75,7 +80,7 @@ def test_tree_kernels_match_oracle_at_batch_size(A, B, wave):
     rng = np.random.default_rng(A * 1000 + B)
     root_hash = rng.integers(1, 2147483647, size=B).astype(np.int64)
     noise = rng.dirichlet(np.full(A, 0.3), size=B) if A != 9 else None
-    trees, _ = run_device_search(g, root_hash, noise, sims, wave)
+    trees, _ = run_device_search(g, root_hash, noise, sims, wave, fused=fused)
     visits, root_value, probs = (t.cpu().numpy() for t in trees.readout())
     assert (visits.sum(1) == sims).all()
     assert (trees.array("root_visit").cpu().numpy() == sims).all()
