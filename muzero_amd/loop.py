@@ -29,10 +29,11 @@ def new_games(worker: SelfPlayWorker, first_frames: torch.Tensor) -> List[GameHi
 
 def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Callable, moves: int,
                temperature: float = 1.0) -> None:
-    """``env_step(actions int array [B]) -> (frames uint8 [B,H,W,3] tensor, rewards [B])``.
-    The phase ends by truncation after ``moves`` moves: as in the reference, the step that ends
-    an episode is not recorded (train.py:280-282), so every recorded position has search
-    statistics."""
+    """``env_step(actions int array [B]) -> (frames uint8 [B,H,W,3] tensor, rewards [B][, done [B]])``
+    (for a ``HostEnvPool`` p: ``lambda a: (p.step(a), p.rewards, p.terminated | p.truncated)``).
+    As in the reference, the step that ends an episode is not recorded (train.py:280-282) and a
+    finished game records nothing further; after ``moves`` moves every game still running is
+    truncated the same way, so every recorded position has search statistics."""
     frames = None
     for move in range(moves):
         worker.draw_randomness()
@@ -41,15 +42,19 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
         values = res.root_values.cpu().numpy()
         acts = actions.cpu().numpy()
         probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
-        frames, rewards = env_step(acts)
+        stepped = env_step(acts)
+        frames, rewards = stepped[0], stepped[1]
+        ended = np.asarray(stepped[2], bool) if len(stepped) > 2 else np.zeros(len(games), bool)
         host_frames = frames.cpu().numpy()
         for i, g in enumerate(games):
+            if g.done:
+                continue
             g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
             g.policies.append(probs[i].astype(np.float64))
-            if move + 1 < moves:
+            if ended[i] or move + 1 == moves:
+                g.done = True
+            else:
                 g.store_transition(int(acts[i]), host_frames[i], float(rewards[i]))
-    for g in games:
-        g.done = True
 
 
 def save_games(replay: ReplayBuffer, games: List[GameHistory], td_steps: int) -> None:
