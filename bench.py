@@ -121,8 +121,6 @@ def main():
     rank, world, local = mzdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if os.environ.get("MZ_FORCE_DEVICE") is not None:  # rehearsal of N ranks on one GPU (with MZ_DIST_BACKEND=gloo)
-        local = int(os.environ["MZ_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

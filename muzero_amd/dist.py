@@ -23,6 +23,8 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MZ_FORCE_DEVICE") is not None:   # several ranks rehearsing on one GPU (with gloo)
+        local = int(os.environ["MZ_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -41,9 +41,11 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="let MIOpen search its convolution solvers")
     ap.add_argument("--rows", type=int, default=1024 * 6, help="loss rows: batch 1024 x (K+1) unroll steps")
     args = ap.parse_args()
     dev = torch.device("cuda")
+    torch.backends.cudnn.benchmark = args.autotune
     out = {}
 
     # support cross-entropy, forward + gradient in one launch: reads n*601*4 B, writes the same
