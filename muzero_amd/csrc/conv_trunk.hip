@@ -232,6 +232,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
 // barrier per layer.  Workgroups are persistent: each walks images b, b+grid, ...
 // ---------------------------------------------------------------------------
 constexpr int kMaxChain = 20;
+#ifndef MZ_CHAIN_PF
+#define MZ_CHAIN_PF 2
+#endif
 
 struct ChainArgs {
   const __bf16* in;
@@ -297,12 +300,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 
     // first layer's weights are requested before the image so that both are in flight together
     const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk[0]) + (long)wave * WN * 64 + lane;
-    bf16x8 w0[WN], w1[WN];
+    bf16x8 wq[PF][WN];  // wq[0] feeds the current k-step, wq[PF-1] was requested last
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) {
-      w0[nt] = wp[nt * 64];
-      if constexpr (PF == 2) w1[nt] = wp[WSTEP + nt * 64];
-    }
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wp[p * WSTEP + nt * 64];
     wp += PF * WSTEP;
 
     {  // image -> buffer 0 (planar); 72 blocks of (16 pixels x 4 channel chunks)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], cur[mt], acc[mt][nt], 0, 0, 0);
           // issue order inside the step: the two weight loads, then one LDS read of the NEXT
           // step behind every pair of MFMAs of this one (measured +2.5 % over loads-then-MFMAs)
           __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -379,12 +381,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {
-            if constexpr (PF == 2) {
-              w0[nt] = w1[nt];
-              w1[nt] = w2[nt];
-            } else {
-              w0[nt] = w2[nt];
-            }
+#pragma unroll
+            for (int p = 0; p + 1 < PF; ++p) wq[p][nt] = wq[p + 1][nt];
+            wq[PF - 1][nt] = w2[nt];
           }
         }
       }
@@ -396,10 +395,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       if (!last) {
         wp = reinterpret_cast<const bf16x8*>(a.wpk[l + 1]) + (long)wave * WN * 64 + lane;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-          w0[nt] = wp[nt * 64];
-          if constexpr (PF == 2) w1[nt] = wp[WSTEP + nt * 64];
-        }
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wp[p * WSTEP + nt * 64];
         wp += PF * WSTEP;
       }
 
@@ -498,7 +496,7 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
     if (layers[l].add_residual) a.res_mask |= 1u << l;
   }
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv_chain_kernel<8, 2>;
+  auto kern = conv_chain_kernel<8, MZ_CHAIN_PF>;
   constexpr int lds = 2 * kLdsBytes;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain")) return rc;
   const int n_cu = mz::compute_units();

@@ -110,3 +110,50 @@ def test_selfplay_worker_evaluate_mode_and_temperature_zero():
     assert int(worker.mcts.trees.array("root_is_f64").sum()) == B
     v2 = res2.visit_counts.cpu().numpy()
     assert all(v2[i, a] > 0 for i, a in enumerate(actions2.cpu().tolist()))   # only visited actions are drawn
+
+
+@pytest.mark.parametrize("A,B", [(6, 256), (18, 1024), (9, 4096)])
+def test_full_size_search_properties_and_sampled_replay(A, B):
+    """The benchmark configurations at their full sizes: size-independent properties for every game
+    (visit counts sum to the simulation count, one node per simulation, no status flags), the
+    oracle tree replaying the recorded network outputs bit-exactly for a sample of games, and the
+    production one-call search giving the same result as the stepwise one."""
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    from oracle import tree as otree
+    cfg, ref, net = _nets(A)
+    sims = 50
+    worker = SelfPlayWorker(cfg, net, B, sims, 1)
+    env = SyntheticEnv(B, device="cuda", pool=2)
+    worker.reset(env.reset())
+    worker.ring.push(env.step())
+    worker.draw_randomness()
+    m = worker.mcts
+    rng = np.random.default_rng(B)
+    sample = rng.choice(B, size=24, replace=False)
+    idx = torch.from_numpy(sample).cuda()
+    obs = worker.ring.observation(net.act_dtype, out=worker.obs)
+    pri0, _ = net.initial_to_pool(obs, m.pool[0])
+    p0 = pri0[idx].cpu().numpy()
+    m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)
+    m.trees.select()
+    log = []
+    for s in range(sims):
+        p, v, r = net.recurrent_in_pool(m.pool, m.leaf_parent, B, m.leaf_action, m.pool[s + 1])
+        log.append((p[idx].cpu().numpy(), v[idx].cpu().numpy(), r[idx].cpu().numpy()))
+        (m.trees.expand_backup_select if s + 1 < sims else m.trees.expand_backup)(p, v, r, 1, cfg.discount)
+    visits, values, probs = (t.cpu().numpy().copy() for t in m.trees.readout())
+    assert (visits.sum(1) == sims).all() and (visits >= 0).all()
+    assert (m.trees.array("root_visit").cpu().numpy() == sims).all()
+    assert (m.trees.array("num_nodes").cpu().numpy() == sims + 1).all()
+    assert int(m.trees.array("status").abs().sum()) == 0
+    assert np.allclose(probs.sum(1), 1.0, atol=1e-12) and np.isfinite(values).all()
+    noise = worker.noise.cpu().numpy()
+    for j, b in enumerate(sample):
+        it = iter([(l[0][j], float(l[1][j]), float(l[2][j]), None) for l in log])
+        root, _ = otree.search(p0[j], None, lambda h, a, it=it: [next(it)] * len(a), sims, 1, noise=noise[b])
+        assert otree.visit_counts(root).tolist() == visits[b].tolist()
+        assert root.q() == values[b]
+    res = m.run(obs, worker.noise)
+    m.check_status()
+    assert np.array_equal(res.visit_counts.cpu().numpy(), visits)
+    assert np.array_equal(res.root_values.cpu().numpy(), values)
