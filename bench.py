@@ -2,7 +2,7 @@
 """Headline benchmark: MCTS simulations per second of the batched self-play search.
 
 One "step" = one move for every game on every GPU: push one new 96x96x3 frame per
-game into the device frame ring, build the stacked observation, run the search
+game into the device frame ring and the stacked observation, run the search
 (initial inference + `sims` simulations at wave 1, each a distinct recurrent
 inference) and choose an action per game.  Synthetic frames and weights.
 

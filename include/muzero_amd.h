@@ -247,6 +247,15 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 
+/* Rotating form of the stacked observation: obs (bf16 or float) [B][HW][3*D] holds frame slot
+ * s in channels 3s..3s+2; this call writes frames uint8 [B][HW][3], normalised by /255, into
+ * slot `slot` of every pixel (all D slots when fill_all != 0: the reset rule, train.py:49-50).
+ * With `newest` the last slot written, channel 3s+r holds what CustomFrameStack's output
+ * (train.py:62-63) has at channel 3*((s - newest - 1) mod D) + r; a consumer reads it through
+ * input-channel weights permuted the same way. */
+int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
+                      int32_t slot, int32_t fill_all, mz_stream_t stream);
+
 /* prepare_observation (train.py:529-540) for a batch: uint8 NHWC [B][HW][C]
  * -> float32 NCHW [B][C][HW], x / 255 (bit-identical to the float64 divide
  * followed by the float32 cast for all 256 byte values). */

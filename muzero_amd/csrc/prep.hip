@@ -98,6 +98,36 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
   }
 }
 
+// Rotating observation: obs [B][HW][3*D] keeps frame slot s in channels 3s..3s+2 of every pixel,
+// so a new frame costs 3 values per pixel instead of rebuilding the whole stack (the consumer
+// undoes the rotation by permuting its input-channel weights).  One thread per pixel; fill_all
+// writes the frame into every slot (the reset rule, train.py:49-50).
+template <typename OutT>
+__global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
+                                                            OutT* __restrict__ obs, int D, int HW, int slot,
+                                                            int fill_all) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const unsigned char* f = frames + ((long)b * HW + p) * 3;
+  OutT v[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float x = (float)f[r] / 255.0f;
+    if constexpr (sizeof(OutT) == 2) v[r] = f32_to_bf16_rne(x);
+    else v[r] = x;
+  }
+  OutT* o = obs + ((long)b * HW + p) * (3 * D);
+  if (fill_all) {
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) o[3 * d + r] = v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o[3 * slot + r] = v[r];
+  }
+}
+
 // uint8 NHWC [B][HW][C] -> float32 NCHW [B][C][HW], x / 255 (train.py:534-540)
 __global__ void prepare_observation_kernel(const unsigned char* __restrict__ in, float* __restrict__ out, int C,
                                            int HW) {
@@ -154,6 +184,20 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
     hipLaunchKernelGGL(ring_to_obs_kernel<float>, grid, dim3(256), lds, mz::as_stream(stream), ring,
                        static_cast<float*>(out), D, HW, newest_slot);
   return mz::check_launch("mz_ring_to_obs");
+}
+
+int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
+                      int32_t slot, int32_t fill_all, mz_stream_t stream) {
+  MZ_REQUIRE(frames && obs && B > 0 && D > 0 && HW > 0 && B <= 65535, "mz_obs_slot_write: bad arguments");
+  MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
+  const dim3 grid((HW + 255) / 256, B);
+  if (out_is_bf16)
+    hipLaunchKernelGGL(obs_slot_write_kernel<unsigned short>, grid, dim3(256), 0, mz::as_stream(stream), frames,
+                       static_cast<unsigned short*>(obs), D, HW, slot, fill_all);
+  else
+    hipLaunchKernelGGL(obs_slot_write_kernel<float>, grid, dim3(256), 0, mz::as_stream(stream), frames,
+                       static_cast<float*>(obs), D, HW, slot, fill_all);
+  return mz::check_launch("mz_obs_slot_write");
 }
 
 int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,

@@ -26,8 +26,10 @@ def pack_weights(w: torch.Tensor, chunk: int) -> torch.Tensor:
     return torch.cat([x, pad])
 
 
-def conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride, action_vec, actions, mean_out):
-    _lib.call("mz_conv3x3_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(layer.dev["w"]),
+def conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride, action_vec, actions, mean_out, weights=None):
+    """weights: packed fragments to use instead of the layer's own (same shape, e.g. permuted input channels)."""
+    weights = layer.dev["w"] if weights is None else weights
+    _lib.call("mz_conv3x3_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(weights),
               _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out), _lib.ptr(action_vec),
               _lib.ptr(actions), _lib.ptr(mean_out), B, H, W, layer.cin, layer.cout, layer.stride,
               1 if relu else 0, _lib.current_stream())

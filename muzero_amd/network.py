@@ -280,10 +280,11 @@ class MuZeroNetwork:
 
     # ---- kernels
     def _conv(self, layer: ConvLayer, x, out, H, W, relu=True, residual=None, in_slot=None, slot_stride=0,
-              actions=None, mean_out=None):
+              actions=None, mean_out=None, weights=None):
         B = out.shape[0]
+        weights = layer.dev["w"] if weights is None else weights
         if self.precision == "fp32":
-            _lib.call("mz_conv3x3_f32", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(layer.dev["w"]),
+            _lib.call("mz_conv3x3_f32", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(weights),
                       _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out),
                       _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
                       B, H, W, layer.cin, layer.cout, layer.stride, 1 if relu else 0, _lib.current_stream())
@@ -295,7 +296,7 @@ class MuZeroNetwork:
         else:
             from . import mfma
             mfma.conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride,
-                      self.action_vec if actions is not None else None, actions, mean_out)
+                      self.action_vec if actions is not None else None, actions, mean_out, weights)
 
     def _chain_ok(self, convs, H, W) -> bool:
         """True when the fused LDS-resident chain kernel serves these layers."""
@@ -355,8 +356,31 @@ class MuZeroNetwork:
             H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         return H, W
 
-    def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
-        """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W]."""
+    def _rotated_weights(self, layer: ConvLayer, newest: int) -> torch.Tensor:
+        """Device weights of the first convolution for an observation in rotating form
+        (prep.FrameRing.rotating_observation): input channels permuted to the slot order."""
+        cache = layer.dev.get("rot")
+        if cache is None:   # all rotations at once (one per slot; 32 x 0.44 MB for the reference's stem)
+            from .prep import rotation_permutation
+            if layer.cin % 3:
+                raise ValueError("rotating observations need 3 channels per frame")
+            cache = []
+            for r in range(layer.cin // 3):
+                wr = layer.w[:, rotation_permutation(layer.cin // 3, r)]
+                if self.precision == "fp32":
+                    cache.append(wr.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device))
+                else:
+                    from . import mfma
+                    chunk, _ = mfma.kernel_info(self.input_hw[0], self.input_hw[1], layer.cin, layer.cout,
+                                                layer.stride)
+                    cache.append(mfma.pack_weights(wr, chunk).to(self.device))
+            layer.dev["rot"] = cache
+        return cache[newest]
+
+    def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor,
+                  rotation: Optional[int] = None) -> None:
+        """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W].
+        rotation: newest slot of an observation in rotating form (None = reference channel order)."""
         B, H, W, _ = obs_nhwc.shape
         hh, hw = self.hidden_hw(H, W)
         _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, H, W, self.cin))
@@ -377,7 +401,8 @@ class MuZeroNetwork:
             if kind == "conv":
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
                 y = hidden_out if final else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
-                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None)
+                w = self._rotated_weights(item, rotation) if i == 0 and rotation is not None else None
+                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None, weights=w)
                 x, H, W = y, HO, WO
             else:
                 c = item[0].cout
@@ -426,10 +451,10 @@ class MuZeroNetwork:
             cur, spare = y, cur
 
     # ---- search-facing entry points (hidden states stay in the pool)
-    def initial_to_pool(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor):
+    def initial_to_pool(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, rotation: Optional[int] = None):
         B = obs_nhwc.shape[0]
         mean = self._buf("mean", (B, self.W), torch.float32)
-        self.represent(obs_nhwc, hidden_out, mean)
+        self.represent(obs_nhwc, hidden_out, mean, rotation)
         priors, value, _, _, _, _ = self._heads(mean, B, False, False, tag="_root")  # own buffers: they
         return priors, value                                # outlive the recurrent steps that follow
 

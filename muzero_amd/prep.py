@@ -23,6 +23,7 @@ class FrameRing:
         self.ring = torch.zeros(B, depth, H, W, 3, dtype=torch.uint8, device=self.device)
         self.staging = torch.empty(B, H, W, 3, dtype=torch.uint8, device=self.device)
         self.newest = depth - 1
+        self.rot = None  # rotating observation [B, H, W, 3*depth], see enable_rotating
 
     def _stage(self, frames: torch.Tensor) -> torch.Tensor:
         _lib.expect(frames, "frames", torch.uint8, (self.B, self.H, self.W, 3), cuda=False, contiguous=False)
@@ -31,17 +32,44 @@ class FrameRing:
         self.staging.copy_(frames, non_blocking=True)
         return self.staging
 
+    def enable_rotating(self, dtype=torch.bfloat16) -> None:
+        """Also keep the stacked observation in rotating form: frame slot s lives in channels
+        3s..3s+2 of every pixel and a push rewrites only the newest slot (3 values per pixel
+        instead of the whole stack).  Call before ``reset``."""
+        if dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("observation dtype must be bfloat16 or float32")
+        self.rot = torch.zeros(self.B, self.H, self.W, 3 * self.depth, dtype=dtype, device=self.device)
+
+    def _write_rot(self, src: torch.Tensor, fill_all: int) -> None:
+        if self.rot is not None:
+            _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), 1 if self.rot.dtype == torch.bfloat16 else 0,
+                      self.B, self.depth, self.H * self.W, self.newest, fill_all, _lib.current_stream())
+
     def reset(self, frames: torch.Tensor) -> None:
         src = self._stage(frames)
         self.newest = self.depth - 1
         _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
                   0, 1, _lib.current_stream())
+        self._write_rot(src, 1)
 
     def push(self, frames: torch.Tensor) -> None:
         src = self._stage(frames)
         self.newest = (self.newest + 1) % self.depth
         _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
                   self.newest, 0, _lib.current_stream())
+        self._write_rot(src, 0)
+
+    def rotating_observation(self):
+        """(tensor [B, H, W, 3*depth], newest slot): channel 3s+r is channel
+        3*((s - newest - 1) mod depth) + r of ``observation()``."""
+        if self.rot is None:
+            raise ValueError("enable_rotating() was not called")
+        return self.rot, self.newest
+
+    def rotation_permutation(self, newest: int = None) -> torch.Tensor:
+        """perm with observation()[..., perm[j]] == rotating tensor[..., j]."""
+        newest = self.newest if newest is None else newest
+        return rotation_permutation(self.depth, newest)
 
     def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None) -> torch.Tensor:
         """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255."""
@@ -53,6 +81,11 @@ class FrameRing:
         _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
                   self.B, self.depth, self.H * self.W, self.newest, _lib.current_stream())
         return out
+
+
+def rotation_permutation(depth: int, newest: int) -> torch.Tensor:
+    j = torch.arange(3 * depth)
+    return ((j // 3 - newest - 1) % depth) * 3 + j % 3
 
 
 def prepare_observation(observation: torch.Tensor) -> torch.Tensor:

@@ -84,9 +84,9 @@ class BatchedMCTS:
         self.leaf_action = self.trees.array("leaf_action")
         self.fuse_tree_step = True  # False: separate expand_backup and select launches (same results)
 
-    def _search(self, observations: torch.Tensor, noise: Optional[torch.Tensor]) -> None:
+    def _search(self, observations: torch.Tensor, noise: Optional[torch.Tensor], rotation: Optional[int] = None) -> None:
         cfg = self.config
-        priors, value = self.net.initial_to_pool(observations, self.pool[0])
+        priors, value = self.net.initial_to_pool(observations, self.pool[0], rotation)
         self.root_priors, self.root_net_value = priors, value
         self.trees.root_init(priors, noise, cfg.root_exploration_fraction)
         fuse = self.fuse_tree_step
@@ -101,12 +101,14 @@ class BatchedMCTS:
                 self.trees.select()
         self.trees.readout(self.visits, self.root_values, self.probs)
 
-    def run(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None) -> SearchResult:
+    def run(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None,
+            rotation: Optional[int] = None) -> SearchResult:
         """observations: NHWC [B, H, W, C] in the network's activation dtype (e.g. from
         FrameRing.observation).  noise: float64 [B, A] Dirichlet rows, or None for the
-        noise-free search of evaluate() (train.py:456-460).  The returned tensors are
+        noise-free search of evaluate() (train.py:456-460).  rotation: newest slot when
+        ``observations`` is FrameRing.rotating_observation().  The returned tensors are
         reused by the next call."""
-        self._search(observations, noise)
+        self._search(observations, noise, rotation)
         return SearchResult(self.visits, self.root_values, self.probs)
 
     def check_status(self) -> None:

@@ -45,12 +45,15 @@ class SelfPlayWorker:
     """Owns the frame ring, the search and the action choice for B games on one GPU."""
 
     def __init__(self, config, network, batch_size: int, num_simulations: int = 50, wave: int = 1,
-                 frame_stack: int = 32, obs_hw=(96, 96), seed: int = 5678):
+                 frame_stack: int = 32, obs_hw=(96, 96), seed: int = 5678, rotating: bool = True):
         self.config = config
         self.net = network
         self.B = batch_size
         self.A = config.action_space_size
         self.ring = FrameRing(batch_size, frame_stack, obs_hw[0], obs_hw[1], network.device)
+        self.rotating = rotating
+        if rotating:
+            self.ring.enable_rotating(network.act_dtype)   # a move then rewrites 3 of the 96 channels per pixel
         self.mcts = BatchedMCTS(config, network, batch_size, num_simulations, wave, obs_hw)
         self.obs = torch.empty(batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack, dtype=network.act_dtype,
                                device=network.device)
@@ -72,7 +75,10 @@ class SelfPlayWorker:
         """One move for all B games.  Returns (actions int32 [B] on the device, SearchResult)."""
         if new_frames is not None:
             self.ring.push(new_frames)
-        self.ring.observation(self.net.act_dtype, out=self.obs)
-        res: SearchResult = self.mcts.run(self.obs, self.noise if add_noise else None)
+        if self.rotating:
+            obs, newest = self.ring.rotating_observation()
+        else:
+            obs, newest = self.ring.observation(self.net.act_dtype, out=self.obs), None
+        res: SearchResult = self.mcts.run(obs, self.noise if add_noise else None, rotation=newest)
         actions = select_actions(res.visit_counts, temperature, self.u if temperature != 0 else None)
         return actions, res

@@ -126,3 +126,33 @@ def test_chain_kernel_any_batch(B):
         src = t[i]
     torch.cuda.synchronize()
     assert torch.equal(out, t[2])      # same arithmetic in both kernels: bit-identical
+
+
+def test_rotating_observation_equals_the_stacked_one():
+    """The rotating form of the frame stack (3 values rewritten per pixel and move) is the stacked
+    observation with its channels permuted, bit for bit, after a reset and after any number of
+    pushes (ring wrap-around included); the first convolution with equally permuted input-channel
+    weights gives the same hidden state up to the order of its float32 partial sums."""
+    from muzero_amd.prep import FrameRing
+    from tests.test_bf16_gpu import _nets
+    rng = np.random.default_rng(5)
+    B = 3
+    ring = FrameRing(B, 32, 96, 96)
+    ring.enable_rotating(torch.bfloat16)
+    frames = torch.from_numpy(rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8))
+    ring.reset(frames)
+    cfg, ref, net = _nets(6)
+    for n_push in (0, 1, 30, 5):          # 0, 1, 31 and 36 pushes in total: the last wraps the ring
+        for _ in range(n_push):
+            ring.push(torch.from_numpy(rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8)))
+        rot, newest = ring.rotating_observation()
+        true = ring.observation(torch.bfloat16)
+        perm = ring.rotation_permutation().cuda()
+        assert torch.equal(true[..., perm], rot)
+        h_true = torch.empty(B, 12, 12, 256, dtype=torch.bfloat16, device="cuda")
+        h_rot = torch.empty_like(h_true)
+        mean = torch.empty(B, 256, dtype=torch.float32, device="cuda")
+        net.represent(true, h_true, mean)
+        net.represent(rot, h_rot, mean, rotation=newest)
+        d = (h_true.float() - h_rot.float()).abs().max().item()
+        assert d <= 0.02 * h_true.float().abs().max().item()

@@ -216,12 +216,13 @@ def test_selfplay_training_roundtrip():
     loop.save_games(replay, [], cfg.td_steps)
     replay.priorities = list(plain.priorities[:0]) + [1.0] * len(replay.priorities)     # undo the priority update
     np.random.seed(0)
-    before = net.initial_inference(worker.obs.permute(0, 3, 1, 2).float()).policy_logits.clone()
+    obs = worker.ring.observation(net.act_dtype).permute(0, 3, 1, 2).float()
+    before = net.initial_inference(obs).policy_logits.clone()
     metrics = loop.train_steps(learner, replay, 6)
     assert all(np.isfinite(m["total_loss"]) for m in metrics)
     assert min(m["total_loss"] for m in metrics[3:]) < metrics[0]["total_loss"]
     loop.publish(learner, net)
-    after = net.initial_inference(worker.obs.permute(0, 3, 1, 2).float()).policy_logits
+    after = net.initial_inference(obs).policy_logits
     assert not torch.equal(before, after)
     actions, res = worker.step(None)                       # and the search runs on the new weights
     assert int(res.visit_counts.sum()) == B * 10

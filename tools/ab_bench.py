@@ -25,8 +25,8 @@ for _ in range(31):
     w.ring.push(env.step())
 w.draw_randomness()
 
-VARIANTS = {"fused tree step": lambda: setattr(w.mcts, "fuse_tree_step", True),
-            "separate launches": lambda: setattr(w.mcts, "fuse_tree_step", False)}
+VARIANTS = {"rotating observation": lambda: setattr(w, "rotating", True),
+            "rebuilt stack": lambda: setattr(w, "rotating", False)}
 total = {k: 0.0 for k in VARIANTS}
 for k, setup in VARIANTS.items():
     setup()
