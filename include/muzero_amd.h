@@ -167,6 +167,14 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
                     const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
                     int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream);
 
+/* The reference architecture's first convolution (96x96, 3*D = 96 input channels -> 256,
+ * stride 2; model.py:182) reading the rotating, tiled observation of mz_obs_slot_write
+ * directly.  wpk: fragments packed as for mz_conv3x3_bf16 from weights whose input channel
+ * 3s + r is the reference's channel 3*((s - newest - 1) mod D) + r.  out: bf16 NHWC
+ * [B][48][48][256] = ReLU(conv + bias) when relu != 0. */
+int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,
+                        int32_t relu, mz_stream_t stream);
+
 /* A chain of 12x12 256->256 convolutions fused into one kernel with the image
  * resident in LDS: the whole dynamics network (conv_state, bn, resblocks;
  * model.py:236-241) or the 12x12 tail of the representation network
@@ -247,12 +255,13 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 
-/* Rotating form of the stacked observation: obs (bf16 or float) [B][HW][3*D] holds frame slot
- * s in channels 3s..3s+2; this call writes frames uint8 [B][HW][3], normalised by /255, into
- * slot `slot` of every pixel (all D slots when fill_all != 0: the reset rule, train.py:49-50).
- * With `newest` the last slot written, channel 3s+r holds what CustomFrameStack's output
- * (train.py:62-63) has at channel 3*((s - newest - 1) mod D) + r; a consumer reads it through
- * input-channel weights permuted the same way. */
+/* Rotating, tiled form of the stacked observation: obs (bf16 or float)
+ * [B][H][W/16][D][16][3] holds, for row y and 16-pixel tile of x, frame slot s as one run of
+ * 16 pixels x 3 values; this call writes frames uint8 [B][HW][3], normalised by /255, into
+ * slot `slot` (all D slots when fill_all != 0: the reset rule, train.py:49-50).  W must be a
+ * multiple of 16.  With `newest` the last slot written, slot s holds what CustomFrameStack's
+ * output (train.py:62-63) has at channels 3*((s - newest - 1) mod D) + {0,1,2}; a consumer
+ * (mz_conv3x3_bf16_rot) reads it through input-channel weights permuted the same way. */
 int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                       int32_t slot, int32_t fill_all, mz_stream_t stream);
 

@@ -93,7 +93,41 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
   }
 }
 
+// The same window from the rotating, tiled observation [H][W/16][D][16][3] (prep.hip): the
+// patch's 16 output-stride columns are exactly one 16-pixel tile, whose D runs of 96 bytes are
+// read with 16-byte loads and scattered to [pixel][3*D channels] in LDS two bytes at a time;
+// the one halo column on the left comes from the neighbouring tile element by element.
 template <class C>
+__device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, int iy0, int ix0, int tid) {
+  static_assert(C::IW == 17 && C::CIN % 3 == 0 && C::CINC == C::CIN && C::WIN % 16 == 0, "tile = patch width");
+  constexpr int D = C::CIN / 3, TPR = C::WIN / 16;  // slots, tiles per image row
+  const int xt = (ix0 + 1) / 16;
+  constexpr int MAIN = C::IH * D * 6;  // 16-byte units: rows x slots x 6
+  for (int u = tid; u < MAIN; u += C::THREADS) {
+    const int row = u / (D * 6), rem = u - row * (D * 6);
+    const int s = rem / 6, k = rem - s * 6;
+    const int iy = iy0 + row;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < C::HIN)
+      v = *reinterpret_cast<const bf16x8*>(src + (((long)iy * TPR + xt) * D + s) * 48 + k * 8);
+    char* base = lds + (row * C::IW + 1) * C::ROWB + s * 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int el = k * 8 + e, px = el / 3, r = el - px * 3;
+      *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = v[e];
+    }
+  }
+  for (int u = tid; u < C::IH * C::CIN; u += C::THREADS) {  // halo column x = ix0
+    const int row = u / C::CIN, c = u - row * C::CIN;
+    const int s = c / 3, r = c - s * 3;
+    const int iy = iy0 + row;
+    __bf16 v = (__bf16)0.f;
+    if (xt > 0 && iy >= 0 && iy < C::HIN) v = src[(((long)iy * TPR + xt - 1) * D + s) * 48 + 45 + r];
+    *reinterpret_cast<__bf16*>(lds + (row * C::IW) * C::ROWB + c * 2) = v;
+  }
+}
+
+template <class C, bool ROT = false>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
@@ -142,7 +176,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
 
   for (int cc = 0; cc < C::NCC; ++cc) {
     if (cc > 0) __syncthreads();
-    stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
+    if constexpr (ROT) stage_input_rot<C>(lds, src, iy0, ix0, tid);
+    else stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
     __syncthreads();
     // software pipeline: the LDS operand of step st+1 is read while step st's MFMAs run
     bf16x8 afA[MT], afB[MT];
@@ -226,10 +261,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   }
 }
 
-template <class C>
+template <class C, bool ROT = false>
 int launch(const ConvArgs& a, int B, hipStream_t stream) {
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv3x3_bf16_kernel<C>;
+  auto kern = conv3x3_bf16_kernel<C, ROT>;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, configured, "conv3x3_bf16"))
     return rc;
   hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), C::LDS_BYTES, stream, a);
@@ -289,6 +324,14 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<ConvDown1>(a, B, s);
   return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
                   Cout, stride);
+}
+
+int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,
+                        int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(obs_rot && wpk && bias && out && B > 0, "mz_conv3x3_bf16_rot: null tensor or empty batch");
+  ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk), bias, nullptr,
+             static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu};
+  return launch<ConvStem, true>(a, B, mz::as_stream(stream));
 }
 
 int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,

@@ -98,16 +98,18 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
   }
 }
 
-// Rotating observation: obs [B][HW][3*D] keeps frame slot s in channels 3s..3s+2 of every pixel,
-// so a new frame costs 3 values per pixel instead of rebuilding the whole stack (the consumer
-// undoes the rotation by permuting its input-channel weights).  One thread per pixel; fill_all
-// writes the frame into every slot (the reset rule, train.py:49-50).
+// Rotating observation: obs [B][H][W/16][D][16][3] keeps, for every row y and 16-pixel tile of
+// x, frame slot s as one run of 16 pixels x 3 values (96 bytes in bf16), so a new frame is written
+// as whole 32-byte sectors and costs 3 values per pixel instead of rebuilding the stack (the
+// consumer gathers a pixel's 3*D values from the D runs of its tile and undoes the rotation by
+// permuting its input-channel weights).  One thread per pixel; fill_all writes the frame into
+// every slot (the reset rule, train.py:49-50).
 template <typename OutT>
 __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
                                                             OutT* __restrict__ obs, int D, int HW, int slot,
                                                             int fill_all) {
   const int b = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // pixel index y*W + x; W is a multiple of 16
   if (p >= HW) return;
   const unsigned char* f = frames + ((long)b * HW + p) * 3;
   OutT v[3];
@@ -117,14 +119,15 @@ __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char
     if constexpr (sizeof(OutT) == 2) v[r] = f32_to_bf16_rne(x);
     else v[r] = x;
   }
-  OutT* o = obs + ((long)b * HW + p) * (3 * D);
+  // (y, x/16) = p / 16 enumerates the tiles in memory order
+  OutT* o = obs + (((long)b * (HW / 16) + p / 16) * D) * 48 + (p % 16) * 3;
   if (fill_all) {
     for (int d = 0; d < D; ++d)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) o[3 * d + r] = v[r];
+      for (int r = 0; r < 3; ++r) o[d * 48 + r] = v[r];
   } else {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) o[3 * slot + r] = v[r];
+    for (int r = 0; r < 3; ++r) o[slot * 48 + r] = v[r];
   }
 }
 
@@ -189,6 +192,7 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
 int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                       int32_t slot, int32_t fill_all, mz_stream_t stream) {
   MZ_REQUIRE(frames && obs && B > 0 && D > 0 && HW > 0 && B <= 65535, "mz_obs_slot_write: bad arguments");
+  MZ_REQUIRE(HW % 16 == 0, "mz_obs_slot_write: the image width must be a multiple of 16 (HW = %d)", HW);
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
   const dim3 grid((HW + 255) / 256, B);
   if (out_is_bf16)

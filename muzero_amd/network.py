@@ -381,9 +381,22 @@ class MuZeroNetwork:
                   rotation: Optional[int] = None) -> None:
         """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W].
         rotation: newest slot of an observation in rotating form (None = reference channel order)."""
-        B, H, W, _ = obs_nhwc.shape
+        rot_kernel = False
+        if rotation is not None:   # [B, H, W/16, D, 16, 3], see prep.FrameRing.enable_rotating
+            if obs_nhwc.dim() != 6 or obs_nhwc.shape[3] * 3 != self.cin:
+                raise ValueError("a rotating observation is [B, H, W/16, frames, 16, 3]")
+            B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2] * 16
+            _lib.expect(obs_nhwc, "observation", self.act_dtype)
+            first = self.rep_plan[0][1]
+            rot_kernel = (self.precision == "bf16" and (H, W, self.cin, first.cout) == (96, 96, 96, 256))
+            if not rot_kernel:     # validation precision / other shapes: undo the tiling, keep the permuted weights
+                from .prep import untile
+                obs_nhwc = untile(obs_nhwc).contiguous()
+        else:
+            B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2]
         hh, hw = self.hidden_hw(H, W)
-        _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, H, W, self.cin))
+        if not rot_kernel:
+            _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, H, W, self.cin))
         _lib.expect(hidden_out, "hidden_out", self.act_dtype, (B, hh, hw, self.W))
         _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
         x = obs_nhwc
@@ -402,7 +415,11 @@ class MuZeroNetwork:
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
                 y = hidden_out if final else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
                 w = self._rotated_weights(item, rotation) if i == 0 and rotation is not None else None
-                self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None, weights=w)
+                if i == 0 and rot_kernel:
+                    _lib.call("mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w), _lib.ptr(item.dev["bias"]), _lib.ptr(y),
+                              B, 1, _lib.current_stream())
+                else:
+                    self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None, weights=w)
                 x, H, W = y, HO, WO
             else:
                 c = item[0].cout

@@ -33,12 +33,14 @@ class FrameRing:
         return self.staging
 
     def enable_rotating(self, dtype=torch.bfloat16) -> None:
-        """Also keep the stacked observation in rotating form: frame slot s lives in channels
-        3s..3s+2 of every pixel and a push rewrites only the newest slot (3 values per pixel
-        instead of the whole stack).  Call before ``reset``."""
+        """Also keep the stacked observation in rotating, tiled form [B, H, W/16, depth, 16, 3]:
+        a push rewrites only the newest slot (3 values per pixel, as whole 96-byte runs, instead
+        of the whole stack).  Call before ``reset``."""
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("observation dtype must be bfloat16 or float32")
-        self.rot = torch.zeros(self.B, self.H, self.W, 3 * self.depth, dtype=dtype, device=self.device)
+        if self.W % 16:
+            raise ValueError("the rotating observation needs an image width that is a multiple of 16")
+        self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, 16, 3, dtype=dtype, device=self.device)
 
     def _write_rot(self, src: torch.Tensor, fill_all: int) -> None:
         if self.rot is not None:
@@ -60,14 +62,14 @@ class FrameRing:
         self._write_rot(src, 0)
 
     def rotating_observation(self):
-        """(tensor [B, H, W, 3*depth], newest slot): channel 3s+r is channel
-        3*((s - newest - 1) mod depth) + r of ``observation()``."""
+        """(tensor [B, H, W/16, depth, 16, 3], newest slot): slot s holds channels
+        3*((s - newest - 1) mod depth) + {0, 1, 2} of ``observation()``."""
         if self.rot is None:
             raise ValueError("enable_rotating() was not called")
         return self.rot, self.newest
 
     def rotation_permutation(self, newest: int = None) -> torch.Tensor:
-        """perm with observation()[..., perm[j]] == rotating tensor[..., j]."""
+        """perm with observation()[..., perm[j]] == untile(rotating tensor)[..., j]."""
         newest = self.newest if newest is None else newest
         return rotation_permutation(self.depth, newest)
 
@@ -81,6 +83,12 @@ class FrameRing:
         _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
                   self.B, self.depth, self.H * self.W, self.newest, _lib.current_stream())
         return out
+
+
+def untile(rot: torch.Tensor) -> torch.Tensor:
+    """[B, H, W/16, D, 16, 3] -> NHWC [B, H, W, 3*D] with the channels still in slot order."""
+    B, H, T, D, _, _ = rot.shape
+    return rot.permute(0, 1, 2, 4, 3, 5).reshape(B, H, T * 16, 3 * D)
 
 
 def rotation_permutation(depth: int, newest: int) -> torch.Tensor:

@@ -129,11 +129,12 @@ def test_chain_kernel_any_batch(B):
 
 
 def test_rotating_observation_equals_the_stacked_one():
-    """The rotating form of the frame stack (3 values rewritten per pixel and move) is the stacked
-    observation with its channels permuted, bit for bit, after a reset and after any number of
-    pushes (ring wrap-around included); the first convolution with equally permuted input-channel
-    weights gives the same hidden state up to the order of its float32 partial sums."""
-    from muzero_amd.prep import FrameRing
+    """The rotating, tiled form of the frame stack (3 values rewritten per pixel and move) is the
+    stacked observation with its channels permuted, bit for bit, after a reset and after any number
+    of pushes (ring wrap-around included); the first convolution reading it directly through equally
+    permuted input-channel weights gives the same hidden state up to the order of its float32
+    partial sums."""
+    from muzero_amd.prep import FrameRing, untile
     from tests.test_bf16_gpu import _nets
     rng = np.random.default_rng(5)
     B = 3
@@ -148,7 +149,7 @@ def test_rotating_observation_equals_the_stacked_one():
         rot, newest = ring.rotating_observation()
         true = ring.observation(torch.bfloat16)
         perm = ring.rotation_permutation().cuda()
-        assert torch.equal(true[..., perm], rot)
+        assert torch.equal(true[..., perm], untile(rot))
         h_true = torch.empty(B, 12, 12, 256, dtype=torch.bfloat16, device="cuda")
         h_rot = torch.empty_like(h_true)
         mean = torch.empty(B, 256, dtype=torch.float32, device="cuda")

@@ -25,8 +25,15 @@ for _ in range(31):
     w.ring.push(env.step())
 w.draw_randomness()
 
-VARIANTS = {"rotating observation": lambda: setattr(w, "rotating", True),
-            "rebuilt stack": lambda: setattr(w, "rotating", False)}
+_rot = w.ring.rot
+
+
+def _rotating(on):
+    w.rotating = on
+    w.ring.rot = _rot if on else None   # off: the frame stack is rebuilt from the u8 ring every move
+
+
+VARIANTS = {"rotating observation": lambda: _rotating(True), "rebuilt stack": lambda: _rotating(False)}
 total = {k: 0.0 for k in VARIANTS}
 for k, setup in VARIANTS.items():
     setup()
