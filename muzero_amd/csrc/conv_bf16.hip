@@ -275,7 +275,14 @@ int launch(const ConvArgs& a, int B, hipStream_t stream) {
 // other than the 12x12 trunk.  Eight wavefronts per workgroup measured 10-20 % faster than four
 // on the three strided layers (more loads in flight per CU); the 24x24 layer did not care.
 //                     CIN CINC COUT S TH TW  HIN WIN waves/SIMD PF NW
-using ConvStem = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2, 2, 8>;      // representation.conv1
+#ifndef MZ_STEM_TH
+#define MZ_STEM_TH 8
+#define MZ_STEM_TW 8
+#define MZ_STEM_NW 8
+#define MZ_STEM_MINW 2
+#endif
+using ConvStem = Cfg<96, 96, 256, 2, MZ_STEM_TH, MZ_STEM_TW, 96, 96, MZ_STEM_MINW, 2, MZ_STEM_NW>;  // representation.conv1
+using ConvStemRot = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2, 2, 8>;   // the same layer on the rotating, tiled observation
 using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, 2, 2, 8>;   // downsample.0.conv
 using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, 2, 2, 4>;   // downsample.0.blocks
 using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, 2, 2, 8>;  // downsample.1.conv
@@ -331,7 +338,7 @@ int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias,
   MZ_REQUIRE(obs_rot && wpk && bias && out && B > 0, "mz_conv3x3_bf16_rot: null tensor or empty batch");
   ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk), bias, nullptr,
              static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu};
-  return launch<ConvStem, true>(a, B, mz::as_stream(stream));
+  return launch<ConvStemRot, true>(a, B, mz::as_stream(stream));
 }
 
 int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,

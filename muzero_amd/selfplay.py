@@ -55,12 +55,20 @@ class SelfPlayWorker:
         if rotating:
             self.ring.enable_rotating(network.act_dtype)   # a move then rewrites 3 of the 96 channels per pixel
         self.mcts = BatchedMCTS(config, network, batch_size, num_simulations, wave, obs_hw)
-        self.obs = torch.empty(batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack, dtype=network.act_dtype,
-                               device=network.device)
+        self._obs = None
+        self._obs_shape = (batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack)
         self.rng = np.random.default_rng(seed)
         self.noise = torch.empty(batch_size, self.A, dtype=torch.float64, device=network.device)
         self.u = torch.empty(batch_size, dtype=torch.float64, device=network.device)
         self.sims = num_simulations
+
+    @property
+    def obs(self) -> torch.Tensor:
+        """Buffer for the stacked observation in the reference's channel order (allocated on first
+        use: the rotating path never needs it)."""
+        if self._obs is None:
+            self._obs = torch.empty(*self._obs_shape, dtype=self.net.act_dtype, device=self.net.device)
+        return self._obs
 
     def reset(self, frames: torch.Tensor) -> None:
         self.ring.reset(frames)
