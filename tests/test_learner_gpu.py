@@ -226,3 +226,31 @@ def test_selfplay_training_roundtrip():
     assert not torch.equal(before, after)
     actions, res = worker.step(None)                       # and the search runs on the new weights
     assert int(res.visit_counts.sum()) == B * 10
+
+
+def test_episode_store_compaction_keeps_targets_exact():
+    """More than a thousand evictions trigger the store's compaction of its evicted prefix; game
+    indices and targets stay exact across it."""
+    from muzero_amd.learner import EpisodeStore, GameHistory
+    rng = np.random.default_rng(11)
+    store = EpisodeStore(4, 0.997, capacity=8)
+    games = []
+    for _ in range(1200):
+        T = int(rng.integers(1, 6))
+        g = GameHistory(4, 0.997)
+        g.rewards, g.values = list(rng.normal(0, 1, T)), list(rng.normal(0, 1, T))
+        g.policies = list(rng.dirichlet(np.ones(4), T))
+        games.append(g)
+        store.add_game(g)
+    for _ in range(1100):
+        store.pop_front()
+    assert len(store) == 100 and store.base < 1100          # compacted at least once
+    live = games[1100:]
+    q = [(i, int(rng.integers(0, len(g.rewards)))) for i, g in enumerate(live)]
+    tv, tr, tp = (t.cpu().numpy() for t in store.targets([a for a, _ in q], [b for _, b in q], 3, 2))
+    for i, (gi, p) in enumerate(q):
+        for k, (v, r, pol) in enumerate(live[gi].make_target(p, 3, 2)):
+            assert tv[i, k] == v and tr[i, k] == r and np.array_equal(tp[i, k], pol)
+    store.add_game(games[0])                                 # and it keeps growing after compaction
+    tv2, _, _ = store.targets([100], [0], 3, 2)
+    assert tv2.cpu().numpy()[0, 0] == games[0].make_target(0, 3, 2)[0][0]
