@@ -238,6 +238,50 @@ __device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, con
   }
 }
 
+// Same layer with K = 32*KS known at compile time and the weight fragments of a whole output
+// tile requested in one go: the kernel is bound by the latency of its dependent phases, so the
+// first tile's fragments are loaded by the caller before the data they multiply exists, and the
+// next tile's travel while the current tile computes.
+template <int KS>
+struct TileFrags {
+  hbf16x8 f[KS];
+};
+template <int KS>
+__device__ __forceinline__ void load_tile_frags(TileFrags<KS>& fr, const hbf16x8* __restrict__ wp, int t) {
+  const hbf16x8* w = wp + (long)t * KS * 64 + (threadIdx.x & 63);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) fr.f[ks] = w[ks * 64];
+}
+template <int KS>
+__device__ __forceinline__ void dense16_bf16_pre(const hbf16x8* __restrict__ wp, const float* __restrict__ bias,
+                                                 const float* src, int lds, float* dst, int ldd, int tiles,
+                                                 bool relu, TileFrags<KS> cur) {
+  constexpr int NW = kHeadsBlock / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* sp = src + (lane & 15) * lds + (lane >> 4) * 8;
+  for (int t = wave; t < tiles; t += NW) {
+    TileFrags<KS> nxt;
+    if (t + NW < tiles) load_tile_frags<KS>(nxt, wp, t + NW);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      hbf16x8 bfrag;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bfrag[j] = (__bf16)sp[ks * 32 + j];
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.f[ks], bfrag, acc, 0, 0, 0);
+    }
+    const int o = t * 16 + (lane >> 4) * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + o);
+    float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
+    if (relu) {
+      v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+    }
+    float* d = dst + (lane & 15) * ldd + o;
+    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+    if (t + NW < tiles) cur = nxt;
+  }
+}
+
 __device__ __forceinline__ void dense16_any(const float* wp, const float* bias, const float* src, int lds,
                                             float* dst, int ldd, int K, int tiles, bool relu) {
   if (K % 32 == 0) dense16<8>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
@@ -258,17 +302,32 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
   float* logit_s = mean_s;                        // [16][otiles*16+1], reuses the mean once it is consumed
   const int b0 = blockIdx.x * kHeadSamples;
   const int ns = B - b0 < kHeadSamples ? B - b0 : kHeadSamples;
+  // the reference architecture's sizes (256 -> 256 -> O) in bf16: both layers' first weight
+  // fragments are requested before the spatial means are even staged
+  const bool fast = hw.bf16 && C == 256 && Hd == 256;
+  TileFrags<8> f1;
+  if (fast && (int)(threadIdx.x >> 6) < Hd / 16)
+    load_tile_frags<8>(f1, reinterpret_cast<const hbf16x8*>(hw.w1p), threadIdx.x >> 6);
   for (int i = threadIdx.x; i < kHeadSamples * C; i += kHeadsBlock) {
     const int s = i / C, k = i % C;
     mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
   }
   __syncthreads();
+  if (fast) {
+    dense16_bf16_pre<8>(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, Hd / 16, true, f1);
+    TileFrags<8> f2;  // requested before the barrier that publishes the hidden layer
+    if ((int)(threadIdx.x >> 6) < otiles) load_tile_frags<8>(f2, reinterpret_cast<const hbf16x8*>(hw.w2p), threadIdx.x >> 6);
+    __syncthreads();
+    dense16_bf16_pre<8>(reinterpret_cast<const hbf16x8*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, otiles, false, f2);
+    __syncthreads();
+  } else {
   if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   else dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   __syncthreads();
   if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   else dense16_any(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   __syncthreads();
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* lg_out = head == 0 ? policy_logits : (head == 1 ? value_logits : reward_logits);
