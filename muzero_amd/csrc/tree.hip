@@ -59,11 +59,30 @@ TreeView make_view(void* ws, const mz_tree_layout* L) {
 
 __device__ __forceinline__ int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+// max over the 64 lanes of a wavefront, returned in every lane.  Four data-parallel-primitive
+// steps reduce each row of 16 lanes (xor 1, xor 2, half-row mirror, row mirror: every lane of a
+// row ends with the row's maximum), four scalar lane reads combine the rows; about a third of
+// the latency of six cross-lane permutes through the LDS crossbar.  No NaN inputs.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, m);
-  hi = __shfl_xor(hi, m);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                          __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  double o;
+  o = dpp_f64<0xB1>(v);  v = o > v ? o : v;   // quad_perm [1,0,3,2]
+  o = dpp_f64<0x4E>(v);  v = o > v ? o : v;   // quad_perm [2,3,0,1]
+  o = dpp_f64<0x141>(v); v = o > v ? o : v;   // row_half_mirror
+  o = dpp_f64<0x140>(v); v = o > v ? o : v;   // row_mirror
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  const double ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 
 // ---------------------------------------------------------------- root init
@@ -130,19 +149,11 @@ __device__ __forceinline__ void select_game(const TreeView& t, const double* __r
       }
       if (!(score > ninf)) score = ninf;  // NaN and -inf never beat the initial -inf
     }
-    // wavefront argmax, strict '>' in action order == lowest action among equals
-    double best = score;
-    int best_a = lane;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const double os = shfl_xor_f64(best, m);
-      const int oa = __shfl_xor(best_a, m);
-      if (os > best || (os == best && oa < best_a)) {
-        best = os;
-        best_a = oa;
-      }
-    }
-    best_a = wave_uniform(best_a);
+    // wavefront argmax, strict '>' in action order == lowest action among equals: the maximum,
+    // then the first lane that holds it
+    const double best = wave_max_f64(score);
+    const unsigned long long holders = __ballot(score == best);
+    int best_a = holders ? __builtin_ctzll(holders) : 0;
     if (parent_n >= table_len) bad = 3;
     if (!(best > ninf)) {  // the reference would return action -1 / child None here
       bad = 1;
@@ -253,12 +264,8 @@ __device__ __forceinline__ bool expand_backup_game(const TreeView& t, const floa
     t.root_value_sum[b] = ws;
     t.root_visit[b] = n;
   }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    const double ol = shfl_xor_f64(lo, m), oh = shfl_xor_f64(hi, m);
-    lo = ol < lo ? ol : lo;
-    hi = oh > hi ? oh : hi;
-  }
+  lo = -wave_max_f64(-lo);
+  hi = wave_max_f64(hi);
   if (lane == 0) {
     const double plo = t.minmax[2 * b], phi = t.minmax[2 * b + 1];
     t.minmax[2 * b] = lo < plo ? lo : plo;
