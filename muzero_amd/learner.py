@@ -350,34 +350,60 @@ class ReplayBuffer:
         self.alpha = config.priority_alpha
         self.beta = config.priority_beta
         self.buffer: List[GameHistory] = []
-        self.priorities: List[float] = []
+        self._prio = np.empty(1024, np.float64)   # one priority per position, live part [_head, _tail)
+        self._head = self._tail = 0
         self.store = episode_store           # device mirror for batched targets (optional)
 
     def __len__(self):
         return len(self.buffer)
 
+    @property
+    def priorities(self) -> np.ndarray:
+        """One priority per stored position, oldest game first (a view: writes go through)."""
+        return self._prio[self._head:self._tail]
+
+    @priorities.setter
+    def priorities(self, values) -> None:
+        values = np.asarray(values, np.float64)
+        self._prio = values.copy() if len(values) else np.empty(1024, np.float64)
+        self._head, self._tail = 0, len(values)
+
+    def _append(self, values: np.ndarray) -> None:
+        n = len(values)
+        if self._tail + n > len(self._prio):           # compact, then grow if still short
+            live = self._prio[self._head:self._tail]
+            cap = max(len(self._prio), 2 * (len(live) + n))
+            fresh = np.empty(cap, np.float64)
+            fresh[:len(live)] = live
+            self._prio, self._head, self._tail = fresh, 0, len(live)
+        self._prio[self._tail:self._tail + n] = values
+        self._tail += n
+
     def save_game(self, game: GameHistory, priorities: Optional[np.ndarray] = None) -> None:
         if priorities is None:
-            priorities = np.full(len(game.rewards), max(self.priorities) if self.priorities else 1)
+            priorities = np.full(len(game.rewards), self.priorities.max() if self._tail > self._head else 1)
         if len(priorities) != len(game.rewards):
             raise ValueError(f"{len(priorities)} priorities for a game of {len(game.rewards)} positions: the buffer "
                              "keeps exactly one per position (sampling maps flat indices through game lengths)")
         self.buffer.append(game)
-        self.priorities.extend(priorities)
+        self._append(np.asarray(priorities, np.float64))
         if self.store is not None:
             self.store.add_game(game)
         while len(self.buffer) > self.window_size:
             old = self.buffer.pop(0)
-            self.priorities = self.priorities[len(old.rewards):]
+            self._head += len(old.rewards)
             if self.store is not None:
                 self.store.pop_front()
 
     def sample_positions(self, uniforms: Optional[np.ndarray] = None):
         """-> (game index, in-game position, flat index) arrays and importance weights.
-        ``uniforms`` are the [0,1) draws np.random.choice would consume (global generator if None)."""
-        total = sum(self.priorities)
-        n = len(self.priorities)
-        probs = np.array([1 / n] * n if total == 0 else [p / total for p in self.priorities])
+        ``uniforms`` are the [0,1) draws np.random.choice would consume (global generator if None).
+        Same arithmetic as model.py:580-588: sequential sum of the priorities, p / total, inversion
+        of the cumulative distribution as np.random.choice does it."""
+        prio = self.priorities
+        n = len(prio)
+        total = np.cumsum(prio)[-1]                     # left-to-right, as Python's sum()
+        probs = np.full(n, 1 / n) if total == 0 else prio / total
         u = np.random.random_sample(self.batch_size) if uniforms is None else np.asarray(uniforms)
         cdf = np.cumsum(probs)
         cdf /= cdf[-1]
@@ -389,8 +415,8 @@ class ReplayBuffer:
         return gi, flat - starts[gi], flat, weights
 
     def update_priorities(self, flat_indices, priorities) -> None:
-        for idx, p in zip(flat_indices, priorities):
-            self.priorities[int(idx)] = (float(p) + 1e-6) ** self.alpha
+        idx = np.asarray(flat_indices, np.int64)
+        self.priorities[idx] = (np.asarray(priorities, np.float64) + 1e-6) ** self.alpha
 
 
 def compute_priorities(game: GameHistory, td_steps: int) -> np.ndarray:

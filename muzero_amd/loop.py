@@ -57,6 +57,27 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
                 g.store_transition(int(acts[i]), host_frames[i], float(rewards[i]))
 
 
+def evaluate(worker: SelfPlayWorker, first_frames: torch.Tensor, env_step: Callable, max_moves: int) -> np.ndarray:
+    """The reference's evaluation episodes (train.py:433-478) for B games at once: no root noise
+    (train.py:456-460), most-visited action (select_action with temperature 0, train.py:467),
+    rewards summed until each game ends or ``max_moves`` is reached.  ``env_step`` as in
+    ``play_moves`` (it must report ``done``).  Returns the episode returns [B]."""
+    worker.reset(first_frames)
+    total = np.zeros(worker.B)
+    alive = np.ones(worker.B, bool)
+    frames = None
+    for _ in range(max_moves):
+        actions, _ = worker.step(frames, temperature=0, add_noise=False)
+        stepped = env_step(actions.cpu().numpy())
+        frames, rewards = stepped[0], np.asarray(stepped[1], np.float64)
+        total += np.where(alive, rewards, 0.0)
+        if len(stepped) > 2:
+            alive &= ~np.asarray(stepped[2], bool)
+        if not alive.any():
+            break
+    return total
+
+
 def save_games(replay: ReplayBuffer, games: List[GameHistory], td_steps: int) -> None:
     """train.py:286-289.  A game holds one position more than it holds search values (the last
     frame was never searched); the buffer keeps one priority per position, so that position

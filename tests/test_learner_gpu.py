@@ -254,3 +254,25 @@ def test_episode_store_compaction_keeps_targets_exact():
     store.add_game(games[0])                                 # and it keeps growing after compaction
     tv2, _, _ = store.targets([100], [0], 3, 2)
     assert tv2.cpu().numpy()[0, 0] == games[0].make_target(0, 3, 2)[0][0]
+
+
+def test_evaluate_runs_noise_free_greedy_episodes():
+    from muzero_amd import loop
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg = MuZeroConfig()
+    cfg.observation_shape, cfg.action_space_size = (96, 96, 96), 4
+    net = MuZeroNetwork(cfg, precision="bf16", state_dict=init_state_dict(cfg, seed=0))
+    B = 4
+    worker = SelfPlayWorker(cfg, net, B, num_simulations=8)
+    env = SyntheticEnv(B, device="cuda")
+    lens = np.array([2, 3, 5, 9])
+    t = [0]
+
+    def env_step(actions):
+        t[0] += 1
+        return env.step(actions), np.ones(B), t[0] >= lens
+    ret = loop.evaluate(worker, env.reset(), env_step, max_moves=20)
+    assert ret.tolist() == lens.tolist() and t[0] == 9          # reward 1 per move until each game's end
+    assert int(worker.mcts.trees.array("root_is_f64").sum()) == 0   # no exploration noise at the roots
