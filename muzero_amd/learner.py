@@ -441,12 +441,17 @@ def unroll_actions(action_lists, K: int) -> np.ndarray:
 
 class Learner:
     def __init__(self, config, device="cuda", state_dict=None, loss_impl: Optional[str] = None,
-                 precision: str = "fp32"):
+                 precision: str = "fp32", autotune: bool = True):
         """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
         convolutions and linear layers under bfloat16 autocast with float32 master weights,
-        BatchNorm statistics and losses."""
+        BatchNorm statistics and losses.  autotune: see below."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
+        if autotune and torch.device(device).type == "cuda":
+            # let MIOpen time its convolution solvers once per shape (process-wide switch): the
+            # default heuristic picks slow ones for these 12x12 and 24x24 layers (28 -> 22 ms per
+            # bf16 update at batch 128)
+            torch.backends.cudnn.benchmark = True
         self.config = config
         self.precision = precision
         self.device = torch.device(device)
