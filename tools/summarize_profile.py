@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 outputs of tools/profile_round.sh into the committed records:
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_kernels.md (table + dynamics-launch timing),
-profiles/traffic.json (HBM-side bytes per dynamics launch of the dominant kernel)."""
+"""Turn the raw rocprofv3 outputs of tools/profile_round.sh into the records kept under profiles/:
+<tag>_kernel_stats.csv, <tag>_kernels.md (table + dynamics-launch timing) and traffic.json (HBM-side
+bytes per dynamics launch of the dominant kernel).  They are written beside the raw data; copy them."""
 import csv
 import glob
 import json
@@ -11,7 +11,7 @@ import statistics
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
-prof = out   # written beside the raw data (gpurun_out/ is what comes back from the GPU box); copy into profiles/
+prof = out
 
 
 def one(pattern):
