@@ -1,12 +1,12 @@
 // bf16 MFMA 3x3 convolution (padding 1, stride 1 or 2) for gfx950, NHWC.
 //
 // Implicit GEMM with the operands arranged for CDNA4:
-//   * one workgroup (4 wavefronts) owns an output patch of TH x TW pixels of one
+//   * one workgroup (4 or 8 wavefronts) owns an output patch of TH x TW pixels of one
 //     image and ALL output channels; the input window of the patch (with its
 //     zero halo) is staged ONCE in LDS and then read 9 times, once per filter
 //     tap, as MFMA operand fragments (ds_read_b128, rows padded by 16 B so that
 //     the 16 pixels of a fragment fall on different bank groups);
-//   * the four wavefronts split the output channels, so weight fragments are
+//   * the wavefronts split the output channels, so weight fragments are
 //     private to a wavefront: they are pre-packed on the host in fragment order
 //     and stream straight from L2 into registers (1 KiB contiguous per
 //     wave-instruction), never through LDS;
