@@ -235,6 +235,9 @@ constexpr int kMaxChain = 20;
 #ifndef MZ_CHAIN_PF
 #define MZ_CHAIN_PF 2
 #endif
+#ifndef MZ_CHAIN_NW
+#define MZ_CHAIN_NW 8
+#endif
 
 struct ChainArgs {
   const __bf16* in;
@@ -496,12 +499,12 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
     if (layers[l].add_residual) a.res_mask |= 1u << l;
   }
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv_chain_kernel<8, MZ_CHAIN_PF>;
+  auto kern = conv_chain_kernel<MZ_CHAIN_NW, MZ_CHAIN_PF>;
   constexpr int lds = 2 * kLdsBytes;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain")) return rc;
   const int n_cu = mz::compute_units();
   const int grid = B < n_cu ? B : n_cu;  // one persistent workgroup per CU (all of its LDS)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MZ_CHAIN_NW), lds, stream, a);
   return mz::check_launch("mz_conv_chain_bf16");
 }
 }  // namespace mz
