@@ -238,6 +238,14 @@ constexpr int kMaxChain = 20;
 #ifndef MZ_CHAIN_NW
 #define MZ_CHAIN_NW 8
 #endif
+// -DMZ_CHAIN_STAMPS builds a diagnostic variant (tools/chain_phase_stamps.py): two workgroups
+// record the shader clock at the phase boundaries of every layer.
+#ifdef MZ_CHAIN_STAMPS
+__device__ long long g_stamps[8192];
+#define MZ_STAMP(i) if (stamp) g_stamps[sidx + (i)] = clock64()
+#else
+#define MZ_STAMP(i)
+#endif
 
 struct ChainArgs {
   const __bf16* in;
@@ -332,6 +340,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 
 #pragma unroll 1
     for (int l = 0; l < a.n_layers; ++l) {
+#ifdef MZ_CHAIN_STAMPS
+      const bool stamp = (blockIdx.x == 7 || blockIdx.x == 130) && lane == 0 && (wave == 0 || wave == 5) && l < 8;
+      const int sidx = ((((blockIdx.x == 130) * 2 + (wave == 5)) * 4 + ((b / (int)gridDim.x) & 3)) * 8 + l) * 4;
+#endif
+      MZ_STAMP(0);  // layer start
       const char* sbuf = lds + (l & 1) * kLdsBytes;
       char* dbuf = lds + ((l + 1) & 1) * kLdsBytes;
       const bool last = l == a.n_layers - 1;
@@ -392,6 +405,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       }
 
       touched ^= pf0 ^ pf1;
+      MZ_STAMP(1);  // main loop done
       // next layer's first weight fragments travel while this layer's epilogue runs
       const float* bias = a.bias[l];
       const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
@@ -440,7 +454,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           }
         }
       }
+      MZ_STAMP(2);  // epilogue done
       __syncthreads();
+      MZ_STAMP(3);  // barrier passed
     }
 
     {  // final buffer -> global, same (16 pixels x 4 chunks) blocks as the load
@@ -469,6 +485,12 @@ int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef MZ_CHAIN_STAMPS
+extern "C" int mz_debug_read_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
+}
+#endif
 
 namespace mz {
 // called by mz_conv3x3_bf16 for the 12x12x256->256 stride-1 shape
