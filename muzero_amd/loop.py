@@ -34,27 +34,34 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
     As in the reference, the step that ends an episode is not recorded (train.py:280-282) and a
     finished game records nothing further; after ``moves`` moves every game still running is
     truncated the same way, so every recorded position has search statistics."""
+    B = len(games)
     frames = None
+    V, P, Aq, R, F, E = [], [], [], [], [], []
     for move in range(moves):
         worker.draw_randomness()
         actions, res = worker.step(frames, temperature)
         counts = res.visit_counts.cpu().numpy()
-        values = res.root_values.cpu().numpy()
+        V.append(res.root_values.cpu().numpy().copy())
         acts = actions.cpu().numpy()
-        probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
+        P.append(counts / np.maximum(counts.sum(1, keepdims=True), 1))
         stepped = env_step(acts)
-        frames, rewards = stepped[0], stepped[1]
-        ended = np.asarray(stepped[2], bool) if len(stepped) > 2 else np.zeros(len(games), bool)
-        host_frames = frames.cpu().numpy()
-        for i, g in enumerate(games):
-            if g.done:
-                continue
-            g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
-            g.policies.append(probs[i].astype(np.float64))
-            if ended[i] or move + 1 == moves:
-                g.done = True
-            else:
-                g.store_transition(int(acts[i]), host_frames[i], float(rewards[i]))
+        frames = stepped[0]
+        Aq.append(acts)
+        R.append(np.array(stepped[1], np.float64))           # copies: an environment pool reuses its arrays
+        E.append(np.array(stepped[2], bool) if len(stepped) > 2 else np.zeros(B, bool))
+        F.append(frames.cpu().numpy() if frames.is_cuda else frames.numpy().copy())
+    # hand every game its moves in one go (the per-move work above stays free of per-game Python)
+    V, R, E, Aq = np.stack(V), np.stack(R), np.stack(E), np.stack(Aq)
+    E[moves - 1] = True                                      # the phase ends by truncation
+    for i, g in enumerate(games):
+        if g.done:
+            continue
+        last = int(np.argmax(E[:, i]))                       # first move that ends this game
+        g.values.extend(V[:last + 1, i].tolist())            # store_search_stats, train.py:83-87
+        g.policies.extend(P[m][i].astype(np.float64) for m in range(last + 1))
+        for m in range(last):                                # the ending move itself is not recorded
+            g.store_transition(int(Aq[m, i]), F[m][i], float(R[m, i]))
+        g.done = True
 
 
 def evaluate(worker: SelfPlayWorker, first_frames: torch.Tensor, env_step: Callable, max_moves: int) -> np.ndarray:

@@ -54,3 +54,46 @@ def test_pool_rejects_wrong_shapes():
     with pytest.raises(ValueError):
         bad.reset()
     pool.close(); bad.close()
+
+
+def test_play_moves_records_like_the_reference_loop():
+    """loop.play_moves against a stub worker: every game gets search statistics for each position it
+    reached, the move that ends a game is not recorded as a transition, and frames coming from an
+    environment pool's reused buffers are copied."""
+    import torch
+    from muzero_amd import loop
+    from muzero_amd.learner import GameHistory
+
+    B, A = 5, 3
+
+    class Res:
+        def __init__(self, t):
+            self.visit_counts = torch.tensor([[t + 1, 1, 0]] * B, dtype=torch.int32)
+            self.root_values = torch.full((B,), float(t), dtype=torch.float64)
+
+    class Worker:
+        def __init__(self):
+            self.t = 0
+
+        def draw_randomness(self):
+            pass
+
+        def step(self, frames, temperature):
+            self.t += 1
+            return torch.full((B,), self.t % A, dtype=torch.int32), Res(self.t)
+
+    pool = HostEnvPool(lambda i: FakeEnv(i, False), B, workers=2, frame_shape=(8, 8, 3), pin=False)
+    first = pool.reset()
+    games = [GameHistory(A, 0.997, frame_stack=4) for _ in range(B)]
+    for g, f in zip(games, first.numpy().copy()):
+        g.store_transition(None, f, 0)
+    loop.play_moves(Worker(), games, lambda a: (pool.step(a), pool.rewards, pool.terminated | pool.truncated), 6)
+    for i, g in enumerate(games):
+        n = min(3 + i, 6)                       # FakeEnv i ends at its move 3 + i; the phase truncates at 6
+        assert g.done and len(g.values) == n and len(g.policies) == n
+        assert len(g.rewards) == n and len(g.actions) == n      # reset entry + n - 1 transitions
+        assert g.values == [float(t) for t in range(1, n + 1)]
+        assert [int(f[0, 0, 0]) for f in g.frames] == [(i * 16 + t) % 256 for t in range(n)]
+        assert g.actions[1:] == [t % A for t in range(1, n)]
+        assert abs(g.policies[0].sum() - 1) < 1e-12
+    pool.close()
