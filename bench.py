@@ -74,16 +74,20 @@ def cpu_baseline(cfg, sd, sims, budget_s=20.0):
 def measure_dynamics_kernel(worker, one_step, moves=2):
     """Average duration of the dominant kernel - the fused dynamics chain (5 convolutions
     12x12x256->256 with the image resident in LDS) - measured in place: HIP events on the launch
-    stream around every dynamics launch of `moves` further moves of the same workload."""
+    stream around every dynamics launch of `moves` further moves of the same workload.  The tree
+    and heads launches of the same moves are timed the same way (secondary kernels)."""
     net = worker.net
-    net.dynamics_events = []
+    net.dynamics_events, net.heads_events, worker.mcts.tree_events = [], [], []
     for _ in range(moves):
         one_step()
     torch.cuda.synchronize()
     pairs, net.dynamics_events = net.dynamics_events, None
-    total_ms = sum(e0.elapsed_time(e1) for e0, e1 in pairs)
+    heads, net.heads_events = net.heads_events, None
+    tree, worker.mcts.tree_events = worker.mcts.tree_events, None
+    mean_s = lambda ps: sum(e0.elapsed_time(e1) for e0, e1 in ps) / max(len(ps), 1) * 1e-3
     n_convs = 1 + 2 * len(net.dyn_blocks)
-    return total_ms / len(pairs) * 1e-3, n_convs, len(pairs)  # s per launch, convs per launch, launches
+    # s per launch, convs per launch, launches, (tree s per launch, heads s per launch)
+    return mean_s(pairs), n_convs, len(pairs), (mean_s(tree), mean_s(heads))
 
 
 def load_profiled_traffic():
@@ -196,7 +200,7 @@ def main():
             "env_frames_per_sec": 4 * world * B * args.steps / elapsed,
             "visit_sum_check": visits_ok,
         }
-        dur, n_convs, n_launches = measure_dynamics_kernel(worker, lambda: worker.step(env.step())[0])
+        dur, n_convs, n_launches, (tree_s, heads_s) = measure_dynamics_kernel(worker, lambda: worker.step(env.step())[0])
         flops = TRUNK_FLOPS * n_convs * B
         achieved = flops / dur / 1e12
         prof = load_profiled_traffic()
@@ -209,6 +213,17 @@ def main():
                            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                            "launch_us": dur * 1e6, "launches_timed": n_launches, "flops_per_launch": flops,
                            "end_to_end_frac": sims_per_s / world * 953.98e6 / (PEAK_BF16_TFLOPS * 1e12)}
+        # the other launches of a simulation step, timed the same way (HIP events include ~2 us of
+        # launch latency).  Tree: algorithmic bytes per simulation = D*(A*20+20) read by the descent
+        # + A*20+12 written by the expansion + (D+1)*32 for the backup at mean depth D ~ 4.
+        tree_bytes = B * (4 * (A * 20 + 20) + A * 20 + 12 + 5 * 32)
+        out["secondary_kernels"] = [
+            {"kernel": "expand_backup_select_kernel (tree step)", "bound": "hbm (latency-bound dependent loads)",
+             "launch_us": tree_s * 1e6, "achieved": tree_bytes / tree_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+             "frac": tree_bytes / tree_s / 8e12},
+            {"kernel": "heads_kernel (3 MLPs + softmax + support decode)", "bound": "latency (4 dependent phases)",
+             "launch_us": heads_s * 1e6},
+        ]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args.sims, args.cpu_seconds)
             out["speedup_vs_cpu"] = sims_per_s / out["cpu_baseline"]["value"]

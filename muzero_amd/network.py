@@ -201,6 +201,7 @@ class MuZeroNetwork:
         self._buffers: Dict[tuple, torch.Tensor] = {}
         self._chains: Dict[str, tuple] = {}
         self.dynamics_events = None  # set to a list to time every fused dynamics launch with HIP events
+        self.heads_events = None     # the same for the heads launch of every recurrent step
         self.input_hw = tuple(input_hw)
         self.load_state_dict(state_dict if state_dict is not None else init_state_dict(config, seed))
 
@@ -479,7 +480,14 @@ class MuZeroNetwork:
         B = hidden_out.shape[0]
         mean = self._buf("mean", (B, self.W), torch.float32)
         self.dynamics(pool, in_slot, slot_stride, actions, hidden_out, mean)
+        timing = self.heads_events
+        if timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         priors, value, reward, _, _, _ = self._heads(mean, B, True, False)
+        if timing is not None:
+            e1.record()
+            timing.append((e0, e1))
         return priors, value, reward
 
     # ---- the reference's call surface (NCHW float32 in and out)

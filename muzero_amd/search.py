@@ -83,6 +83,7 @@ class BatchedMCTS:
         self.leaf_parent = self.trees.array("leaf_parent")
         self.leaf_action = self.trees.array("leaf_action")
         self.fuse_tree_step = True  # False: separate expand_backup and select launches (same results)
+        self.tree_events = None     # set to a list to time every tree launch of the search loop with HIP events
 
     def _search(self, observations: torch.Tensor, noise: Optional[torch.Tensor], rotation: Optional[int] = None) -> None:
         cfg = self.config
@@ -96,7 +97,14 @@ class BatchedMCTS:
                                                                 self.leaf_action, self.pool[s + 1])
             # the descent of the next simulation rides in the same launch as this one's backup
             step = self.trees.expand_backup_select if fuse and s + 1 < self.steps else self.trees.expand_backup
+            timing = self.tree_events
+            if timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             step(priors, value, reward, self.wave, cfg.discount)
+            if timing is not None:
+                e1.record()
+                timing.append((e0, e1))
             if not fuse and s + 1 < self.steps:
                 self.trees.select()
         self.trees.readout(self.visits, self.root_values, self.probs)
