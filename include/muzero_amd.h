@@ -245,9 +245,11 @@ int mz_nhwc_to_nchw_f32(const float* in, float* out, int32_t B, int32_t C, int32
 /* ring: uint8 [B][D][frame_bytes] device ring of the last D frames per game;
  * frames: uint8 [B][frame_bytes] the new frame of every game (device memory,
  * typically the target of a pinned async copy).  Writes slot `slot`, or every
- * slot when fill_all != 0 (reset replicates the first frame, train.py:49-50). */
+ * slot when fill_all != 0 (reset replicates the first frame, train.py:49-50).
+ * fill_mask (optional, int32 [B]): games with a non-zero entry are reset that way while the
+ * others push - concurrent games end their episodes at different moves. */
 int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int64_t frame_bytes, int32_t slot,
-                 int32_t fill_all, mz_stream_t stream);
+                 int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream);
 
 /* Stacked, normalised observation from the ring: out[b][pixel][age*3 + rgb] =
  * frame(age)[pixel][rgb] / 255 with age 0 = oldest = slot (newest_slot+1) % D
@@ -258,12 +260,13 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
 /* Rotating, tiled form of the stacked observation: obs (bf16 or float)
  * [B][H][W/16][D][16][3] holds, for row y and 16-pixel tile of x, frame slot s as one run of
  * 16 pixels x 3 values; this call writes frames uint8 [B][HW][3], normalised by /255, into
- * slot `slot` (all D slots when fill_all != 0: the reset rule, train.py:49-50).  W must be a
+ * slot `slot` (all D slots when fill_all != 0, or for the games flagged in the optional
+ * fill_mask int32 [B]: the reset rule, train.py:49-50).  W must be a
  * multiple of 16.  With `newest` the last slot written, slot s holds what CustomFrameStack's
  * output (train.py:62-63) has at channels 3*((s - newest - 1) mod D) + {0,1,2}; a consumer
  * (mz_conv3x3_bf16_rot) reads it through input-channel weights permuted the same way. */
 int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
-                      int32_t slot, int32_t fill_all, mz_stream_t stream);
+                      int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream);
 
 /* prepare_observation (train.py:529-540) for a batch: uint8 NHWC [B][HW][C]
  * -> float32 NCHW [B][C][HW], x / 255 (bit-identical to the float64 divide

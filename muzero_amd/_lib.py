@@ -53,10 +53,11 @@ _SIGNATURES = {
     "mz_support_ce": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "mz_nstep_targets": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_double, _P, _P, _P, _P]),
-    "mz_ring_push": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "mz_ring_push": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "mz_ring_to_obs": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_conv3x3_bf16_rot": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
-    "mz_obs_slot_write": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_obs_slot_write": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                    _P]),
     "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
 }
 

@@ -14,8 +14,10 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 // ring [B][D][frame_bytes]; frames [B][frame_bytes].  fill_all != 0 copies the
 // frame into every slot (the reset rule, train.py:49-50).
 __global__ void ring_push_kernel(unsigned char* __restrict__ ring, const unsigned char* __restrict__ frames,
-                                 int D, long frame_bytes, int slot, int fill_all) {
+                                 int D, long frame_bytes, int slot, int fill_all,
+                                 const int* __restrict__ fill_mask) {
   const int b = blockIdx.y;
+  if (fill_mask && fill_mask[b]) fill_all = 1;  // this game starts a new episode
   const uint4* src = reinterpret_cast<const uint4*>(frames + (long)b * frame_bytes);
   const long n16 = frame_bytes / 16;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
@@ -107,10 +109,11 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
 template <typename OutT>
 __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
                                                             OutT* __restrict__ obs, int D, int HW, int slot,
-                                                            int fill_all) {
+                                                            int fill_all, const int* __restrict__ fill_mask) {
   const int b = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;  // pixel index y*W + x; W is a multiple of 16
   if (p >= HW) return;
+  if (fill_mask && fill_mask[b]) fill_all = 1;  // this game starts a new episode
   const unsigned char* f = frames + ((long)b * HW + p) * 3;
   OutT v[3];
 #pragma unroll
@@ -154,13 +157,13 @@ __global__ void prepare_observation_kernel(const unsigned char* __restrict__ in,
 extern "C" {
 
 int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int64_t frame_bytes, int32_t slot,
-                 int32_t fill_all, mz_stream_t stream) {
+                 int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream) {
   MZ_REQUIRE(ring && frames && B > 0 && D > 0 && B <= 65535, "mz_ring_push: bad arguments");
   MZ_REQUIRE(frame_bytes > 0 && frame_bytes % 16 == 0, "mz_ring_push: frame_bytes must be a multiple of 16");
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_ring_push: slot %d outside ring of depth %d", slot, D);
   const int blocks = (int)((frame_bytes / 16 + 255) / 256);
   hipLaunchKernelGGL(ring_push_kernel, dim3(blocks, B), dim3(256), 0, mz::as_stream(stream), ring, frames, D,
-                     (long)frame_bytes, slot, fill_all);
+                     (long)frame_bytes, slot, fill_all, fill_mask);
   return mz::check_launch("mz_ring_push");
 }
 
@@ -190,17 +193,17 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
 }
 
 int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
-                      int32_t slot, int32_t fill_all, mz_stream_t stream) {
+                      int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream) {
   MZ_REQUIRE(frames && obs && B > 0 && D > 0 && HW > 0 && B <= 65535, "mz_obs_slot_write: bad arguments");
   MZ_REQUIRE(HW % 16 == 0, "mz_obs_slot_write: the image width must be a multiple of 16 (HW = %d)", HW);
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
   const dim3 grid((HW + 255) / 256, B);
   if (out_is_bf16)
     hipLaunchKernelGGL(obs_slot_write_kernel<unsigned short>, grid, dim3(256), 0, mz::as_stream(stream), frames,
-                       static_cast<unsigned short*>(obs), D, HW, slot, fill_all);
+                       static_cast<unsigned short*>(obs), D, HW, slot, fill_all, fill_mask);
   else
     hipLaunchKernelGGL(obs_slot_write_kernel<float>, grid, dim3(256), 0, mz::as_stream(stream), frames,
-                       static_cast<float*>(obs), D, HW, slot, fill_all);
+                       static_cast<float*>(obs), D, HW, slot, fill_all, fill_mask);
   return mz::check_launch("mz_obs_slot_write");
 }
 

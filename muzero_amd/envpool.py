@@ -19,7 +19,11 @@ import torch
 
 class HostEnvPool:
     def __init__(self, make_env: Callable[[int], object], num_envs: int, workers: int = 8,
-                 frame_shape=(96, 96, 3), pin: bool = None):
+                 frame_shape=(96, 96, 3), pin: bool = None, auto_reset: bool = False):
+        """auto_reset: an environment whose episode ends in a step is reset within that step, which
+        then returns the NEW episode's first frame with ``restarted[i]`` set (reward and end flags
+        are the ended episode's; its terminal frame is dropped - the reference never records it,
+        train.py:280-282), so B games keep playing without waiting for the longest one."""
         self.envs: List[object] = [make_env(i) for i in range(num_envs)]
         self.B = num_envs
         self.frame_shape = tuple(frame_shape)
@@ -37,6 +41,8 @@ class HostEnvPool:
         self.terminated = np.zeros(num_envs, bool)
         self.truncated = np.zeros(num_envs, bool)
         self.finished = np.zeros(num_envs, bool)      # episodes that ended earlier and were not reset
+        self.auto_reset = auto_reset
+        self.restarted = np.zeros(num_envs, bool)     # this step returned the first frame of a new episode
 
     def _newest(self, obs) -> np.ndarray:
         obs = np.asarray(obs)
@@ -75,15 +81,19 @@ class HostEnvPool:
 
         def work(sl):
             for i in sl:
+                self.restarted[i] = False
                 if self.finished[i]:
                     out[i] = prev[i]
                     self.rewards[i], self.terminated[i], self.truncated[i] = 0.0, False, False
                     continue
                 obs, r, term, trunc, _ = self.envs[i].step(int(actions[i]))
-                out[i] = self._newest(obs)
                 self.rewards[i], self.terminated[i], self.truncated[i] = float(r), bool(term), bool(trunc)
+                if self.auto_reset and (term or trunc):
+                    obs, _ = self.envs[i].reset()
+                    self.restarted[i] = True
+                out[i] = self._newest(obs)
         self._run(work)
-        self.finished |= self.terminated | self.truncated
+        self.finished |= (self.terminated | self.truncated) & ~self.restarted
         return self._buffers[self._cur]
 
     def all_done(self) -> bool:

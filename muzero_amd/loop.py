@@ -20,7 +20,7 @@ from .selfplay import SelfPlayWorker
 def new_games(worker: SelfPlayWorker, first_frames: torch.Tensor) -> List[GameHistory]:
     """Reset the frame rings and open one episode record per game (train.py:214-222)."""
     worker.reset(first_frames)
-    host = first_frames.cpu().numpy()
+    host = first_frames.cpu().numpy() if first_frames.is_cuda else first_frames.numpy().copy()   # a pool reuses its buffers
     games = [GameHistory(worker.A, worker.config.discount, worker.ring.depth) for _ in range(worker.B)]
     for g, f in zip(games, host):
         g.store_transition(None, f, 0)
@@ -62,6 +62,41 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
         for m in range(last):                                # the ending move itself is not recorded
             g.store_transition(int(Aq[m, i]), F[m][i], float(R[m, i]))
         g.done = True
+
+
+def play_continuous(worker: SelfPlayWorker, pool, moves: int, on_game_end: Callable,
+                    temperature: float = 1.0) -> int:
+    """B games that never wait for each other: ``pool`` is a ``HostEnvPool(auto_reset=True)``; a
+    game whose episode ends is handed to ``on_game_end(game)`` (e.g. ``replay.save_game``), its
+    environment has already restarted, its frame stack is refilled from the new episode's first
+    frame (per-game reset on the device) and a fresh record is opened - the reference plays
+    every batch of games to the end of the longest one (train.py:227).  Recording follows
+    train.py:268 / :280-282.  Returns the number of finished games."""
+    games = new_games(worker, pool.reset())
+    frames, restarted, finished = None, None, 0
+    for _ in range(moves):
+        worker.draw_randomness()
+        actions, res = worker.step(frames, temperature, restarted=restarted)
+        counts = res.visit_counts.cpu().numpy()
+        values = res.root_values.cpu().numpy()
+        acts = actions.cpu().numpy()
+        probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
+        frames = pool.step(acts)
+        host = frames.numpy()
+        ended = pool.terminated | pool.truncated
+        restarted = pool.restarted.copy() if pool.restarted.any() else None
+        for i, g in enumerate(games):
+            g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
+            g.policies.append(probs[i].astype(np.float64))
+            if ended[i]:                                      # the ending move is not recorded (train.py:281)
+                g.done = True
+                on_game_end(g)
+                finished += 1
+                games[i] = GameHistory(worker.A, worker.config.discount, worker.ring.depth)
+                games[i].store_transition(None, host[i].copy(), 0)
+            else:
+                g.store_transition(int(acts[i]), host[i].copy(), float(pool.rewards[i]))
+    return finished
 
 
 def evaluate(worker: SelfPlayWorker, first_frames: torch.Tensor, env_step: Callable, max_moves: int) -> np.ndarray:

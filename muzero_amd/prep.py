@@ -42,24 +42,31 @@ class FrameRing:
             raise ValueError("the rotating observation needs an image width that is a multiple of 16")
         self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, 16, 3, dtype=dtype, device=self.device)
 
-    def _write_rot(self, src: torch.Tensor, fill_all: int) -> None:
+    def _write_rot(self, src: torch.Tensor, fill_all: int, mask: torch.Tensor = None) -> None:
         if self.rot is not None:
             _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), 1 if self.rot.dtype == torch.bfloat16 else 0,
-                      self.B, self.depth, self.H * self.W, self.newest, fill_all, _lib.current_stream())
+                      self.B, self.depth, self.H * self.W, self.newest, fill_all, _lib.ptr(mask), _lib.current_stream())
 
     def reset(self, frames: torch.Tensor) -> None:
         src = self._stage(frames)
         self.newest = self.depth - 1
         _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
-                  0, 1, _lib.current_stream())
+                  0, 1, None, _lib.current_stream())
         self._write_rot(src, 1)
 
-    def push(self, frames: torch.Tensor) -> None:
+    def push(self, frames: torch.Tensor, restarted: torch.Tensor = None) -> None:
+        """Append the newest frame of every game.  ``restarted`` (bool / int [B], optional) marks
+        games whose frame is the first of a NEW episode: their whole stack is refilled with it
+        (the reset rule) while the other games just push - games end at different moves."""
         src = self._stage(frames)
+        mask = None
+        if restarted is not None:
+            mask = torch.as_tensor(restarted).to(self.device, torch.int32, non_blocking=True).contiguous()
+            _lib.expect(mask, "restarted", torch.int32, (self.B,))
         self.newest = (self.newest + 1) % self.depth
         _lib.call("mz_ring_push", _lib.ptr(self.ring), _lib.ptr(src), self.B, self.depth, self.frame_bytes,
-                  self.newest, 0, _lib.current_stream())
-        self._write_rot(src, 0)
+                  self.newest, 0, _lib.ptr(mask), _lib.current_stream())
+        self._write_rot(src, 0, mask)
 
     def rotating_observation(self):
         """(tensor [B, H, W/16, depth, 16, 3], newest slot): slot s holds channels

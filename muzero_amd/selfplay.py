@@ -79,10 +79,12 @@ class SelfPlayWorker:
         self.noise.copy_(torch.from_numpy(self.rng.dirichlet(np.full(self.A, alpha), size=self.B)), non_blocking=True)
         self.u.copy_(torch.from_numpy(self.rng.random(self.B)), non_blocking=True)
 
-    def step(self, new_frames: Optional[torch.Tensor], temperature: float = 1.0, add_noise: bool = True):
-        """One move for all B games.  Returns (actions int32 [B] on the device, SearchResult)."""
+    def step(self, new_frames: Optional[torch.Tensor], temperature: float = 1.0, add_noise: bool = True,
+             restarted: Optional[torch.Tensor] = None):
+        """One move for all B games.  Returns (actions int32 [B] on the device, SearchResult).
+        ``restarted`` marks games for which ``new_frames`` holds the first frame of a new episode."""
         if new_frames is not None:
-            self.ring.push(new_frames)
+            self.ring.push(new_frames, restarted)
         if self.rotating:
             obs, newest = self.ring.rotating_observation()
         else:

@@ -50,7 +50,7 @@ def test_argument_validation_needs_no_gpu():
         ("mz_conv3x3_bf16", (None, None, 0) + (None,) * 7 + (1, 12, 12, 256, 256, 1, 1, None), "null tensor"),
         ("mz_conv_chain_bf16", (C.c_void_p(8), None, 0, None, 5, C.c_void_p(8), None, None, None, 4, None), "null"),
         ("mz_heads", (None, 4, 256, 256, 6, 300) + (None,) * 10, "null argument"),
-        ("mz_ring_push", (C.c_void_p(8), C.c_void_p(8), 4, 32, 27647, 0, 0, None), "multiple of 16"),
+        ("mz_ring_push", (C.c_void_p(8), C.c_void_p(8), 4, 32, 27647, 0, 0, None, None), "multiple of 16"),
         ("mz_ring_to_obs", (C.c_void_p(8), C.c_void_p(8), 1, 4, 32, 9216, 32, None), "outside the ring"),
         ("mz_prepare_observation", (None, None, 1, 96, 9216, None), "bad arguments"),
         ("mz_support_to_scalar", (None, 4, 300, None, None), "bad arguments"),

@@ -157,3 +157,30 @@ def test_rotating_observation_equals_the_stacked_one():
         net.represent(rot, h_rot, mean, rotation=newest)
         d = (h_true.float() - h_rot.float()).abs().max().item()
         assert d <= 0.02 * h_true.float().abs().max().item()
+
+
+def test_per_game_restart_refills_only_the_flagged_stacks():
+    """push(frames, restarted): flagged games get the reset rule (every slot = the new frame), the
+    others an ordinary push; both the u8 ring's stacked observation and the rotating one agree
+    with a host model of 5 independent frame stacks."""
+    from muzero_amd.prep import FrameRing, untile
+    rng = np.random.default_rng(9)
+    B, D = 5, 32
+    ring = FrameRing(B, D, 96, 96)
+    ring.enable_rotating(torch.bfloat16)
+    new = lambda: rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8)
+    f = new()
+    ring.reset(torch.from_numpy(f))
+    stacks = [[f[b]] * D for b in range(B)]                  # host model: oldest first
+    for step in range(40):
+        f = new()
+        mask = rng.random(B) < 0.15 if step % 3 else np.zeros(B, bool)
+        ring.push(torch.from_numpy(f), torch.from_numpy(mask) if mask.any() else None)
+        for b in range(B):
+            stacks[b] = [f[b]] * D if mask[b] else stacks[b][1:] + [f[b]]
+    want = np.stack([np.concatenate(s, axis=2) for s in stacks])            # [B, 96, 96, 96] uint8
+    got = ring.observation(torch.float32).cpu().numpy()
+    assert np.array_equal(got, (want.astype(np.float32) / np.float32(255.0)))
+    rot, newest = ring.rotating_observation()
+    perm = ring.rotation_permutation().cuda()
+    assert torch.equal(ring.observation(torch.bfloat16)[..., perm], untile(rot))

@@ -97,3 +97,63 @@ def test_play_moves_records_like_the_reference_loop():
         assert g.actions[1:] == [t % A for t in range(1, n)]
         assert abs(g.policies[0].sum() - 1) < 1e-12
     pool.close()
+
+
+def test_pool_auto_reset_restarts_finished_games():
+    pool = HostEnvPool(lambda i: FakeEnv(i, False), 3, workers=2, frame_shape=(8, 8, 3), pin=False, auto_reset=True)
+    pool.reset()
+    for _ in range(2):
+        pool.step(np.zeros(3, int))
+    f = pool.step(np.ones(3, int))                          # env 0 ends (3 steps) and restarts in the same step
+    assert pool.terminated.tolist() == [True, False, False] and pool.restarted.tolist() == [True, False, False]
+    assert int(f[0, 0, 0, 0]) == 0 and pool.rewards[0] == 1 and pool.envs[0].t == 0
+    f = pool.step(np.ones(3, int))                          # env 1 ends now; env 0 is one step into its new episode
+    assert pool.restarted.tolist() == [False, True, False] and int(f[0, 0, 0, 0]) == 1 and int(f[1, 0, 0, 0]) == 16
+    assert not pool.finished.any() and not pool.all_done()
+    pool.close()
+
+
+def test_play_continuous_hands_over_finished_games_and_restarts_them():
+    import torch
+    from muzero_amd import loop
+
+    B, A = 3, 3
+
+    class Res:
+        def __init__(self, t):
+            self.visit_counts = torch.tensor([[t + 1, 1, 0]] * B, dtype=torch.int32)
+            self.root_values = torch.full((B,), float(t), dtype=torch.float64)
+
+    class Ring:
+        depth = 4
+
+    class Cfg:
+        discount = 0.997
+
+    class Worker:
+        A, B, config, ring = 3, 3, Cfg, Ring
+
+        def __init__(self):
+            self.t, self.masks = 0, []
+
+        def reset(self, frames):
+            pass
+
+        def draw_randomness(self):
+            pass
+
+        def step(self, frames, temperature, restarted=None):
+            self.t += 1
+            self.masks.append(None if restarted is None else restarted.tolist())
+            return torch.full((B,), self.t % A, dtype=torch.int32), Res(self.t)
+
+    pool = HostEnvPool(lambda i: FakeEnv(i, False), B, workers=1, frame_shape=(8, 8, 3), pin=False, auto_reset=True)
+    done, w = [], Worker()
+    n = loop.play_continuous(w, pool, 8, done.append)
+    # episode lengths 3, 4, 5: env 0 ends at moves 3 and 6, env 1 at 4 and 8, env 2 at 5
+    assert n == 5 and [len(g.values) for g in done] == [3, 4, 5, 3, 4]
+    for g in done:
+        assert g.done and len(g.rewards) == len(g.values) == len(g.policies)
+        assert [int(f[0, 0, 0]) % 16 for f in g.frames] == list(range(len(g.frames)))   # frames 0..n-1 of ONE episode
+    assert w.masks[3] == [True, False, False] and w.masks[4] == [False, True, False] and w.masks[1] is None
+    pool.close()
