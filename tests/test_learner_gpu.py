@@ -276,3 +276,54 @@ def test_evaluate_runs_noise_free_greedy_episodes():
     ret = loop.evaluate(worker, env.reset(), env_step, max_moves=20)
     assert ret.tolist() == lens.tolist() and t[0] == 9          # reward 1 per move until each game's end
     assert int(worker.mcts.trees.array("root_is_f64").sum()) == 0   # no exploration noise at the roots
+
+
+def test_continuous_selfplay_on_the_device():
+    """play_continuous with a real worker: episodes of different lengths end, are handed over with
+    search statistics for every position, and a restarted game's frame stack on the device holds
+    only frames of its new episode."""
+    from muzero_amd import loop
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.envpool import HostEnvPool
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.selfplay import SelfPlayWorker
+
+    class Env:
+        """Frames carry (episode, step) in two channels; episode i ends after 3 + i steps."""
+
+        def __init__(self, idx):
+            self.idx, self.ep, self.t = idx, -1, 0
+
+        def _obs(self):
+            f = np.zeros((96, 96, 3), np.uint8)
+            f[..., 0], f[..., 1], f[..., 2] = self.ep, self.t, self.idx
+            return f
+
+        def reset(self):
+            self.ep, self.t = self.ep + 1, 0
+            return self._obs(), {}
+
+        def step(self, a):
+            self.t += 1
+            return self._obs(), 1.0, self.t >= 3 + self.idx, False, {}
+
+    cfg = MuZeroConfig()
+    cfg.observation_shape, cfg.action_space_size = (96, 96, 96), 4
+    net = MuZeroNetwork(cfg, precision="bf16", state_dict=init_state_dict(cfg, seed=0))
+    B = 4
+    worker = SelfPlayWorker(cfg, net, B, num_simulations=6)
+    pool = HostEnvPool(Env, B, workers=2, auto_reset=True)
+    done = []
+    n = loop.play_continuous(worker, pool, 9, done.append)
+    assert n == len(done) == 3 + 2 + 1 + 1                    # lengths 3, 4, 5, 6 within 9 moves
+    for g in done:
+        idx = int(g.frames[0][0, 0, 2])
+        assert len(g.values) == len(g.rewards) == 3 + idx and abs(g.policies[0].sum() - 1) < 1e-12
+        assert len({int(f[0, 0, 0]) for f in g.frames}) == 1                       # one episode's frames only
+        assert [int(f[0, 0, 1]) for f in g.frames] == list(range(3 + idx))
+    obs = worker.ring.observation(torch.float32).cpu().numpy()                    # [B, 96, 96, 96]
+    for i in range(B):
+        episodes = np.round(obs[i, 0, 0, 0::3] * 255).astype(int)                 # channel 0 of the 32 frames
+        # the frames of the final environment step are not in the stack yet (the next move pushes them)
+        assert len(set(episodes.tolist())) == 1 and episodes[0] == pool.envs[i].ep - int(pool.restarted[i])
+    pool.close()
