@@ -64,6 +64,54 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
         g.done = True
 
 
+class _ContinuousGroup:
+    """One worker + one auto-resetting environment pool and the episode records of their games.
+    A move is: ``launch`` (enqueue the search, no wait) -> ``record`` the previous move on the host
+    while the GPU works -> ``fetch`` the search result -> step the environments -> ``stepped``."""
+
+    def __init__(self, worker: SelfPlayWorker, pool, on_game_end: Callable):
+        self.worker, self.pool, self.on_game_end = worker, pool, on_game_end
+        self.games = new_games(worker, pool.reset())
+        self.frames = self.restarted = self._search = self._last = None
+        self.finished = 0
+
+    def launch(self, temperature: float) -> None:
+        self.worker.draw_randomness()
+        self._search = self.worker.step(self.frames, temperature, restarted=self.restarted)
+
+    def fetch(self):
+        """Wait for the search; returns host arrays (actions, root values, visit distributions)."""
+        actions, res = self._search
+        counts = res.visit_counts.cpu().numpy()
+        probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
+        self._last = (actions.cpu().numpy(), res.root_values.cpu().numpy().copy(), probs)
+        return self._last[0]
+
+    def stepped(self, frames) -> None:
+        """The environments were stepped with the last actions: next move's input."""
+        self.frames = frames
+        self.restarted = self.pool.restarted.copy() if self.pool.restarted.any() else None
+        self._flags = ((self.pool.terminated | self.pool.truncated).copy(), self.pool.rewards.copy())
+
+    def record(self) -> None:
+        """Book-keeping of the last move (train.py:268, :280-282); pure host work."""
+        if self._last is None:
+            return
+        (acts, values, probs), self._last = self._last, None
+        (ended, rewards), host, w = self._flags, self.frames.numpy(), self.worker
+        for i, g in enumerate(self.games):
+            g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
+            g.policies.append(probs[i].astype(np.float64))
+            if ended[i]:                                      # the ending move is not recorded (train.py:281)
+                g.done = True
+                self.on_game_end(g)
+                self.finished += 1
+                self.games[i] = GameHistory(w.A, w.config.discount, w.ring.depth)
+                self.games[i].store_transition(None, host[i].copy(), 0)
+            else:
+                g.store_transition(int(acts[i]), host[i].copy(), float(rewards[i]))
+
+
 def play_continuous(worker: SelfPlayWorker, pool, moves: int, on_game_end: Callable,
                     temperature: float = 1.0) -> int:
     """B games that never wait for each other: ``pool`` is a ``HostEnvPool(auto_reset=True)``; a
@@ -71,32 +119,40 @@ def play_continuous(worker: SelfPlayWorker, pool, moves: int, on_game_end: Calla
     environment has already restarted, its frame stack is refilled from the new episode's first
     frame (per-game reset on the device) and a fresh record is opened - the reference plays
     every batch of games to the end of the longest one (train.py:227).  Recording follows
-    train.py:268 / :280-282.  Returns the number of finished games."""
-    games = new_games(worker, pool.reset())
-    frames, restarted, finished = None, None, 0
+    train.py:268 / :280-282 and runs on the host while the GPU searches the next position.
+    Returns the number of finished games."""
+    grp = _ContinuousGroup(worker, pool, on_game_end)
     for _ in range(moves):
-        worker.draw_randomness()
-        actions, res = worker.step(frames, temperature, restarted=restarted)
-        counts = res.visit_counts.cpu().numpy()
-        values = res.root_values.cpu().numpy()
-        acts = actions.cpu().numpy()
-        probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
-        frames = pool.step(acts)
-        host = frames.numpy()
-        ended = pool.terminated | pool.truncated
-        restarted = pool.restarted.copy() if pool.restarted.any() else None
-        for i, g in enumerate(games):
-            g.values.append(float(values[i]))                 # store_search_stats, train.py:83-87
-            g.policies.append(probs[i].astype(np.float64))
-            if ended[i]:                                      # the ending move is not recorded (train.py:281)
-                g.done = True
-                on_game_end(g)
-                finished += 1
-                games[i] = GameHistory(worker.A, worker.config.discount, worker.ring.depth)
-                games[i].store_transition(None, host[i].copy(), 0)
-            else:
-                g.store_transition(int(acts[i]), host[i].copy(), float(pool.rewards[i]))
-    return finished
+        grp.launch(temperature)
+        grp.record()
+        grp.stepped(pool.step(grp.fetch()))
+    grp.record()
+    return grp.finished
+
+
+def play_pipelined(workers, pools, moves: int, on_game_end: Callable, temperature: float = 1.0) -> int:
+    """``play_continuous`` for two groups of games that take turns on the GPU: while one group's
+    positions are searched, the other group's environments are stepped on the host (a background
+    thread; emulators release the GIL), so the emulation time disappears behind the search
+    instead of adding to it (the reference alternates the two serially, train.py:262 / :279).
+    ``workers`` / ``pools``: two of each, one per group.  ``moves`` counts moves per group."""
+    from concurrent.futures import ThreadPoolExecutor
+    if len(workers) != 2 or len(pools) != 2:
+        raise ValueError("play_pipelined takes exactly two workers and two pools")
+    groups = [_ContinuousGroup(w, p, on_game_end) for w, p in zip(workers, pools)]
+    stepping = [None, None]                    # future of each group's environment step
+    with ThreadPoolExecutor(max_workers=1) as bg:
+        for _ in range(moves):
+            for k, grp in enumerate(groups):
+                if stepping[k] is not None:    # stepped behind the other group's search
+                    grp.stepped(stepping[k].result())
+                grp.launch(temperature)
+                grp.record()                   # the previous move's book-keeping, behind this search
+                stepping[k] = bg.submit(grp.pool.step, grp.fetch())
+        for k, grp in enumerate(groups):
+            grp.stepped(stepping[k].result())
+            grp.record()
+    return sum(g.finished for g in groups)
 
 
 def evaluate(worker: SelfPlayWorker, first_frames: torch.Tensor, env_step: Callable, max_moves: int) -> np.ndarray:

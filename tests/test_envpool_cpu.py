@@ -157,3 +157,58 @@ def test_play_continuous_hands_over_finished_games_and_restarts_them():
         assert [int(f[0, 0, 0]) % 16 for f in g.frames] == list(range(len(g.frames)))   # frames 0..n-1 of ONE episode
     assert w.masks[3] == [True, False, False] and w.masks[4] == [False, True, False] and w.masks[1] is None
     pool.close()
+
+
+def test_play_pipelined_matches_two_independent_continuous_runs():
+    """Two groups taking turns (search of one behind the environment steps of the other) record
+    exactly what each group records when played on its own."""
+    import torch
+    from muzero_amd import loop
+
+    B, A = 3, 3
+
+    class Res:
+        def __init__(self, t):
+            self.visit_counts = torch.tensor([[t + 1, 1, 0]] * B, dtype=torch.int32)
+            self.root_values = torch.full((B,), float(t), dtype=torch.float64)
+
+    class Ring:
+        depth = 4
+
+    class Cfg:
+        discount = 0.997
+
+    class Worker:
+        A, B, config, ring = 3, 3, Cfg, Ring
+
+        def __init__(self, base):
+            self.t = base
+
+        def reset(self, frames):
+            pass
+
+        def draw_randomness(self):
+            pass
+
+        def step(self, frames, temperature, restarted=None):
+            self.t += 1
+            return torch.full((B,), self.t % A, dtype=torch.int32), Res(self.t)
+
+    def mk_pool(off):
+        return HostEnvPool(lambda i: FakeEnv(i + off, False), B, workers=1, frame_shape=(8, 8, 3), pin=False,
+                           auto_reset=True)
+
+    def summary(games):
+        return sorted((len(g.values), tuple(g.values), tuple(g.actions), tuple(int(f[0, 0, 0]) for f in g.frames))
+                      for g in games)
+
+    solo = []
+    for base, off in ((0, 0), (100, 2)):
+        pool = mk_pool(off)
+        loop.play_continuous(Worker(base), pool, 9, solo.append)
+        pool.close()
+    both, pools = [], [mk_pool(0), mk_pool(2)]
+    n = loop.play_pipelined([Worker(0), Worker(100)], pools, 9, both.append)
+    assert n == len(both) == len(solo) and summary(both) == summary(solo)
+    for p in pools:
+        p.close()
