@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Self-play -> replay -> K-step unrolled training -> fresh weights back into the search, on
 synthetic frames.  One GPU:  python examples/full_loop.py --games 64 --moves 8 --iters 2
-N GPUs (rank 0 trains, all ranks search; the weights travel by one RCCL broadcast):
+N GPUs (all ranks search; rank 0 trains and the weights travel by one RCCL broadcast, or with
+--data-parallel every rank trains on its own replay buffer and the gradients are averaged by one
+RCCL all-reduce per update):
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 examples/full_loop.py
 """
 import argparse
@@ -30,6 +32,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--actions", type=int, default=4)
+    ap.add_argument("--data-parallel", action="store_true", help="every rank trains; gradients all-reduced")
     args = ap.parse_args()
 
     rank, world, local = mzdist.init_from_env()
@@ -40,7 +43,8 @@ def main():
     cfg.num_simulations, cfg.batch_size = args.sims, args.batch
     sd = mzdist.broadcast_state_dict(init_state_dict(cfg, seed=rank), src=0)
     net = MuZeroNetwork(cfg, precision="bf16", device=dev, state_dict=sd)
-    learner = Learner(cfg, device=dev, state_dict=sd) if rank == 0 else None
+    trains = rank == 0 or args.data_parallel
+    learner = Learner(cfg, device=dev, state_dict=sd, data_parallel=args.data_parallel) if trains else None
     replay = ReplayBuffer(cfg)
     worker = SelfPlayWorker(cfg, net, args.games, args.sims, seed=100 + rank)
     env = SyntheticEnv(args.games, seed=7 + rank, device=dev)
@@ -55,10 +59,13 @@ def main():
         loop.play_moves(worker, games, env_step, args.moves, cfg.visit_softmax_temperature_fn(it))
         torch.cuda.synchronize()
         t1 = time.time()
-        if rank == 0:
+        if trains:
             loop.save_games(replay, games, cfg.td_steps)
             metrics = loop.train_steps(learner, replay, args.train_steps)
-        loop.publish(learner, net)
+        if args.data_parallel:
+            net.load_state_dict(learner.state_dict())     # replicas are identical after averaged updates
+        else:
+            loop.publish(learner, net)
         torch.cuda.synchronize()
         if rank == 0:
             m = metrics[-1]

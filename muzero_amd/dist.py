@@ -104,3 +104,28 @@ def max_over_ranks(value: float) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def average_gradients(parameters) -> None:
+    """Data-parallel training: ONE all-reduce of all gradients as a flat float32 buffer
+    (62 MB for the reference architecture), then the mean is written back in place.  A no-op
+    without an initialised process group.  Parameters without a gradient count as zeros."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = [p for p in parameters]
+    if not params:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1).float()
+                      for p in params]).to(dev)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    off = 0
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p).to(p.device, p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += n

@@ -441,7 +441,7 @@ def unroll_actions(action_lists, K: int) -> np.ndarray:
 
 class Learner:
     def __init__(self, config, device="cuda", state_dict=None, loss_impl: Optional[str] = None,
-                 precision: str = "fp32", autotune: bool = True):
+                 precision: str = "fp32", autotune: bool = True, data_parallel: bool = False):
         """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
         convolutions and linear layers under bfloat16 autocast with float32 master weights,
         BatchNorm statistics and losses.  autotune: see below."""
@@ -453,6 +453,7 @@ class Learner:
             # bf16 update at batch 128)
             torch.backends.cudnn.benchmark = True
         self.config = config
+        self.data_parallel = data_parallel   # every rank trains on its own batch; gradients are averaged
         self.precision = precision
         self.device = torch.device(device)
         self.loss_impl = loss_impl or ("hip" if self.device.type == "cuda" else "torch")
@@ -552,6 +553,9 @@ class Learner:
         loss = per.mean()
         self.optimizer.zero_grad()
         loss.backward()
+        if self.data_parallel:
+            from . import dist as mzdist
+            mzdist.average_gradients(self.network.parameters())     # one all-reduce per update
         torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.config.max_grad_norm)
         self.optimizer.step()
         self.scheduler.step()

@@ -38,6 +38,51 @@ print("rank", rank, "ok")
 '''
 
 
+DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MZ_ROOT"])
+import numpy as np, torch
+from muzero_amd import dist as mzdist
+from muzero_amd.config import MuZeroConfig
+from muzero_amd.learner import Learner
+from muzero_amd.network import init_state_dict
+
+rank, world, local = mzdist.init_from_env("gloo")
+cfg = MuZeroConfig(); cfg.num_channels = 16; cfg.downsample_steps = [(8, 1), (16, 1)]
+cfg.fc_reward_layers = cfg.fc_value_layers = cfg.fc_policy_layers = [16]; cfg.support_size = 5
+cfg.observation_shape = (6, 16, 16); cfg.action_space_size = 4; cfg.num_unroll_steps = 2
+sd = init_state_dict(cfg, seed=3)
+
+
+def batch(r):
+    rng = np.random.default_rng(50 + r)
+    B, K, A = 3, 2, 4
+    return (torch.from_numpy(rng.random((B, 6, 16, 16), dtype=np.float32)), rng.integers(0, A, (B, K)),
+            rng.normal(0, 2, (B, K + 1)), rng.normal(0, 1, (B, K + 1)), rng.dirichlet(np.ones(A), (B, K + 1)), np.ones(B))
+
+
+# what the averaged gradient must be: the mean of the two ranks' own gradients
+grads = []
+for r in range(world):
+    solo = Learner(cfg, device="cpu", state_dict=sd, loss_impl="torch")
+    solo.losses_from_tensors(*batch(r))[3].mean().backward()
+    grads.append([p.grad.clone() for p in solo.network.parameters()])
+want = [sum(g) / world for g in zip(*grads)]
+
+dp = Learner(cfg, device="cpu", state_dict=sd, loss_impl="torch", data_parallel=True)
+dp.losses_from_tensors(*batch(rank))[3].mean().backward()
+mzdist.average_gradients(dp.network.parameters())
+for p, w in zip(dp.network.parameters(), want):
+    assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-8)
+# a full update keeps the replicas identical
+dp.optimizer.zero_grad()
+dp.update_from_tensors(*batch(rank))
+assert mzdist.verify_same_everywhere({k: v for k, v in dp.state_dict().items() if "running" not in k and "num_batches" not in k})
+torch.distributed.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -55,6 +100,22 @@ def test_weight_broadcast_and_sharding_world_size_2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_data_parallel_update_averages_gradients_world_size_2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MZ_ROOT=ROOT, OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
