@@ -62,10 +62,7 @@ def main():
         if trains:
             loop.save_games(replay, games, cfg.td_steps)
             metrics = loop.train_steps(learner, replay, args.train_steps)
-        if args.data_parallel:
-            net.load_state_dict(learner.state_dict())     # replicas are identical after averaged updates
-        else:
-            loop.publish(learner, net)
+        loop.publish(learner, net)   # rank 0's weights (and BatchNorm statistics) reach every search engine
         torch.cuda.synchronize()
         if rank == 0:
             m = metrics[-1]
