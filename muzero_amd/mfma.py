@@ -26,6 +26,17 @@ def pack_weights(w: torch.Tensor, chunk: int) -> torch.Tensor:
     return torch.cat([x, pad])
 
 
+def pack_weights_batch(w: torch.Tensor, chunk: int) -> torch.Tensor:
+    """pack_weights for a stack of weight tensors [n][Cout][Cin][3][3] on whatever device they are
+    on -> [n][packed length]; row i equals pack_weights(w[i], chunk)."""
+    n, cout, cin = w.shape[0], w.shape[1], w.shape[2]
+    ncc, kc, nt = cin // chunk, chunk // 32, cout // 16
+    x = w.to(torch.bfloat16).permute(0, 3, 4, 2, 1).reshape(n, 9, ncc, kc, 4, 8, nt, 16)
+    x = x.permute(0, 2, 1, 3, 6, 4, 7, 5).reshape(n, -1)
+    pad = torch.zeros(n, 2 * nt * 512, dtype=torch.bfloat16, device=w.device)
+    return torch.cat([x, pad], dim=1).contiguous()
+
+
 def conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride, action_vec, actions, mean_out, weights=None):
     """weights: packed fragments to use instead of the layer's own (same shape, e.g. permuted input channels)."""
     weights = layer.dev["w"] if weights is None else weights

@@ -361,20 +361,19 @@ class MuZeroNetwork:
         """Device weights of the first convolution for an observation in rotating form
         (prep.FrameRing.rotating_observation): input channels permuted to the slot order."""
         cache = layer.dev.get("rot")
-        if cache is None:   # all rotations at once (one per slot; 32 x 0.44 MB for the reference's stem)
+        if cache is None:   # all rotations at once, on the device (32 x 0.44 MB for the reference's stem)
             from .prep import rotation_permutation
             if layer.cin % 3:
                 raise ValueError("rotating observations need 3 channels per frame")
-            cache = []
-            for r in range(layer.cin // 3):
-                wr = layer.w[:, rotation_permutation(layer.cin // 3, r)]
-                if self.precision == "fp32":
-                    cache.append(wr.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device))
-                else:
-                    from . import mfma
-                    chunk, _ = mfma.kernel_info(self.input_hw[0], self.input_hw[1], layer.cin, layer.cout,
-                                                layer.stride)
-                    cache.append(mfma.pack_weights(wr, chunk).to(self.device))
+            D = layer.cin // 3
+            perms = torch.stack([rotation_permutation(D, r) for r in range(D)]).to(self.device)   # [D][Cin]
+            wr = layer.w.to(self.device)[:, perms].permute(1, 0, 2, 3, 4)                           # [D][Cout][Cin][3][3]
+            if self.precision == "fp32":
+                cache = wr.permute(0, 3, 4, 2, 1).reshape(D, 9, layer.cin, layer.cout).contiguous()
+            else:
+                from . import mfma
+                chunk, _ = mfma.kernel_info(self.input_hw[0], self.input_hw[1], layer.cin, layer.cout, layer.stride)
+                cache = mfma.pack_weights_batch(wr, chunk)
             layer.dev["rot"] = cache
         return cache[newest]
 
