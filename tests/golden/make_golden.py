@@ -331,16 +331,27 @@ def action_cases(n=600):
     print("g6 ok")
 
 
+TREE_CASES = {
+    # name: (A, sims, wave, noise, games, seed)
+    "a6_w1_noise": (6, 50, 1, True, 8, 100),
+    "a18_w1_noise": (18, 50, 1, True, 8, 200),
+    "a9_w1_plain": (9, 50, 1, False, 8, 300),
+    "a6_w50_noise": (6, 50, 50, True, 4, 400),
+    "a18_w5_noise": (18, 50, 5, True, 4, 500),
+    "a4_w1_deep": (4, 200, 1, True, 4, 600),
+    "a9_w2_noise": (9, 50, 2, True, 4, 700),
+    "a64_w1_noise": (64, 80, 1, True, 3, 800),
+}
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    tree_case("a6_w1_noise", 6, 50, 1, True, 8, 100)
-    tree_case("a18_w1_noise", 18, 50, 1, True, 8, 200)
-    tree_case("a9_w1_plain", 9, 50, 1, False, 8, 300)
-    tree_case("a6_w50_noise", 6, 50, 50, True, 4, 400)
-    tree_case("a18_w5_noise", 18, 50, 5, True, 4, 500)
-    tree_case("a4_w1_deep", 4, 200, 1, True, 4, 600)
-    decode_cases()
-    ucb_cases()
-    action_cases()
-    nets_small()
-    nets_full()
+    only = sys.argv[1:]            # names of tree cases to (re)generate; none = everything
+    for name, spec in TREE_CASES.items():
+        if not only or name in only:
+            tree_case(name, *spec)
+    if not only:
+        decode_cases()
+        ucb_cases()
+        action_cases()
+        nets_small()
+        nets_full()

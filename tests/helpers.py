@@ -7,7 +7,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 HASH_MOD = 2147483647
 TREE_CASES = ["a6_w1_noise", "a18_w1_noise", "a9_w1_plain", "a6_w50_noise",
-              "a18_w5_noise", "a4_w1_deep"]
+              "a18_w5_noise", "a4_w1_deep", "a9_w2_noise", "a64_w1_noise"]
 
 
 def load(name):
