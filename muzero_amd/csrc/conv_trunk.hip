@@ -232,6 +232,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
 // barrier per layer.  Workgroups are persistent: each walks images b, b+grid, ...
 // ---------------------------------------------------------------------------
 constexpr int kMaxChain = 20;
+
+// lanes (bit l: lane l, pixel mt*16 + l%16 of a row-major 12-wide image) whose pixel sits in column x_edge
+__host__ __device__ constexpr unsigned long long edge_lanes(int mt, int x_edge) {
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if ((mt * 16 + (l & 15)) % kSide == x_edge) m |= 1ull << l;
+  return m;
+}
+
 #ifndef MZ_CHAIN_PF
 #define MZ_CHAIN_PF 2
 #endif
@@ -268,22 +277,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int WN = 16 / NW;
   constexpr int WSTEP = 16 * 64;
-  constexpr int KOFF = 4 * kPlaneB;
+  constexpr int KOFF = kPlaneB;  // LDS bytes between consecutive 32-channel k-steps
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
 
-  auto tap_addresses = [&](int tap, int (&addr)[kMT]) {
+  // LDS byte address of the 16-byte operand a lane reads for pixel tile mt under a tap: the pixel
+  // tile's own slot shifted by the tap, which for a neighbour above the first or below the last
+  // row lands in the 16 zero pixels between planes.  Only two kinds of lane need redirecting to a
+  // zero pixel by hand: those whose left / right neighbour belongs to another row (a fixed lane
+  // pattern per tile: edge_lanes) and, for the upward taps, the first row of the very first plane,
+  // which has no zero pixels in front of it.  Planes are ordered so that a k-step's four planes are
+  // 8 planes apart and the k-step index is a small immediate offset.
+  const int vb0 = kq * (8 * kPlaneB) + r16 * 16;
+  auto tap_addresses = [&](int tap, int buf_off, int (&addr)[kMT]) {
     const int dy = tap / 3, dx = tap - dy * 3;
+    const int t = vb0 + (buf_off + ((dy - 1) * kSide + (dx - 1)) * 16);
+    const int z = vb0 + (buf_off + kPix * 16);
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
-      const int m = mt * 16 + r16;
-      const int py = m / kSide, px = m - py * kSide;
-      const bool ok = (unsigned)(py + dy - 1) < (unsigned)kSide && (unsigned)(px + dx - 1) < (unsigned)kSide;
-      const int q = m + (dy - 1) * kSide + (dx - 1);
-      addr[mt] = kq * kPlaneB + (ok ? q : kPix + (q & 15)) * 16;
+      unsigned long long bad = dx == 0 ? edge_lanes(mt, 0) : dx == 2 ? edge_lanes(mt, kSide - 1) : 0ull;
+      if (mt == 0 && dy == 0) bad |= 0x0FFF0FFF0FFF0FFFull;
+      addr[mt] = __builtin_amdgcn_inverse_ballot_w64(bad) ? z : t + mt * 256;
     }
   };
+  auto plane_of = [](int q) { return (q & 3) * 8 + (q >> 2); };  // channel chunk q -> plane
 
   // zero pixels of both buffers (never written afterwards)
   {
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
           v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
         }
-        *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v;
+        *reinterpret_cast<bf16x8*>(lds + plane_of(q) * kPlaneB + pix * 16) = v;
       }
     }
     __syncthreads();
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       const int sidx = ((((blockIdx.x == 130) * 2 + (wave == 5)) * 4 + ((b / (int)gridDim.x) & 3)) * 8 + l) * 4;
 #endif
       MZ_STAMP(0);  // layer start
-      const char* sbuf = lds + (l & 1) * kLdsBytes;
+      const int sbuf_off = (l & 1) * kLdsBytes;
       char* dbuf = lds + ((l + 1) & 1) * kLdsBytes;
       const bool last = l == a.n_layers - 1;
 
@@ -356,10 +374,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
       int aaddr[kMT];
-      tap_addresses(0, aaddr);
-      bf16x8 afA[kMT], afB[kMT];
+      tap_addresses(0, sbuf_off, aaddr);
+      bf16x8 af[kMT];
 #pragma unroll
-      for (int mt = 0; mt < kMT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt]);
+      for (int mt = 0; mt < kMT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt]);
 
       int pf0 = 0, pf1 = 0;
       if (last && nsrc) {  // 576 lines of 128 bytes, 512 threads
@@ -371,21 +389,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
         for (int kc = 0; kc < kKC; ++kc) {
-          bf16x8(&cur)[kMT] = (kc & 1) ? afB : afA;
-          bf16x8(&nxt)[kMT] = (kc & 1) ? afA : afB;
           bf16x8 w2[WN];
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];
           wp += WSTEP;
-          if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, aaddr);  // the next step is the next tap's first
+          if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, sbuf_off, aaddr);  // the next step is the next tap's first
+          // a pixel tile's operand register is refilled for the NEXT step as soon as this step's
+          // MFMAs have read it: one live copy per tile instead of two
 #pragma unroll
-          for (int mt = 0; mt < kMT; ++mt)
-            nxt[mt] = *reinterpret_cast<const bf16x8*>(sbuf + aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
-#pragma unroll
-          for (int mt = 0; mt < kMT; ++mt)
+          for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], cur[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[mt][nt], 0, 0, 0);
+            af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
+          }
           // issue order inside the step: the two weight loads, then one LDS read of the NEXT
           // step behind every pair of MFMAs of this one (measured +2.5 % over loads-then-MFMAs)
           __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       for (int nt = 0; nt < WN; ++nt) {
         const int cbase = (wave * WN + nt) * 16 + kq * 4;
         const float4 bv = *reinterpret_cast<const float4*>(bias + cbase);
-        char* plane = dbuf + (cbase >> 3) * kPlaneB + (cbase & 4) * 2;
+        char* plane = dbuf + plane_of(cbase >> 3) * kPlaneB + (cbase & 4) * 2;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int mt = 0; mt < kMT; ++mt) {
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       for (int j = 0; j < 72 / NW; ++j) {
         const int it = wave + NW * j;
         const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
-        *reinterpret_cast<bf16x8*>(dst + pix * kCh + q * 8) = *reinterpret_cast<const bf16x8*>(fbuf + q * kPlaneB + pix * 16);
+        *reinterpret_cast<bf16x8*>(dst + pix * kCh + q * 8) = *reinterpret_cast<const bf16x8*>(fbuf + plane_of(q) * kPlaneB + pix * 16);
       }
     }
     __syncthreads();  // the next image overwrites buffer 0
