@@ -276,7 +276,7 @@ template <int NW, int PF>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int WN = 16 / NW;
-  constexpr int WSTEP = 16 * 64;
+  constexpr int WSTEP = 16 * 1024;  // bytes of weight fragments per k-step (16 channel tiles x 1 KB)
   constexpr int KOFF = kPlaneB;  // LDS bytes between consecutive 32-channel k-steps
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -328,13 +328,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
     }
 
     // first layer's weights are requested before the image so that both are in flight together
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk[0]) + (long)wave * WN * 64 + lane;
+    // (buffer loads: the layer's base sits in a scalar resource descriptor, the k-step offset in a
+    // scalar register that the scalar unit advances, the lane's own offset never changes - no
+    // vector instruction is spent on weight addresses; reads past the packed array return zero)
+    const int wlane = wave * (WN * 1024) + lane * 16;
+    auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
+    };
+    auto wdesc = [&](int l) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t wr = wdesc(0);
+    int wp = 0;
     bf16x8 wq[PF][WN];  // wq[0] feeds the current k-step, wq[PF-1] was requested last
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-      for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wp[p * WSTEP + nt * 64];
-    wp += PF * WSTEP;
+      for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
+    wp = PF * WSTEP;
 
     {  // image -> buffer 0 (planar); 72 blocks of (16 pixels x 4 channel chunks)
       const int pl = lane & 15, qq = lane >> 4;
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
         for (int kc = 0; kc < kKC; ++kc) {
           bf16x8 w2[WN];
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];
+          for (int nt = 0; nt < WN; ++nt) w2[nt] = wfrag(wr, wp, nt);
           wp += WSTEP;
           if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, sbuf_off, aaddr);  // the next step is the next tap's first
           // a pixel tile's operand register is refilled for the NEXT step as soon as this step's
@@ -427,12 +438,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       const float* bias = a.bias[l];
       const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
       if (!last) {
-        wp = reinterpret_cast<const bf16x8*>(a.wpk[l + 1]) + (long)wave * WN * 64 + lane;
+        wr = wdesc(l + 1);
 #pragma unroll
         for (int p = 0; p < PF; ++p)
 #pragma unroll
-          for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wp[p * WSTEP + nt * 64];
-        wp += PF * WSTEP;
+          for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
+        wp = PF * WSTEP;
       }
 
       // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
