@@ -289,7 +289,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
   // pattern per tile: edge_lanes) and, for the upward taps, the first row of the very first plane,
   // which has no zero pixels in front of it.  Planes are ordered so that a k-step's four planes are
   // 8 planes apart and the k-step index is a small immediate offset.
-  const int vb0 = kq * (8 * kPlaneB) + r16 * 16;
+  // (addresses are LDS byte offsets including the array's own base, used through LDS-typed
+  // pointers, so that no read pays an add of the base)
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int vb0 = lds_base + kq * (8 * kPlaneB) + r16 * 16;
   auto tap_addresses = [&](int tap, int buf_off, int (&addr)[kMT]) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const int t = vb0 + (buf_off + ((dy - 1) * kSide + (dx - 1)) * 16);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       tap_addresses(0, sbuf_off, aaddr);
       bf16x8 af[kMT];
 #pragma unroll
-      for (int mt = 0; mt < kMT; ++mt) af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt]);
+      for (int mt = 0; mt < kMT; ++mt) af[mt] = *(lds_frag_ptr)(aaddr[mt]);
 
       int pf0 = 0, pf1 = 0;
       if (last && nsrc) {  // 576 lines of 128 bytes, 512 threads
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[mt][nt], 0, 0, 0);
-            af[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
+            af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
           }
           // issue order inside the step: the two weight loads, then one LDS read of the NEXT
           // step behind every pair of MFMAs of this one (measured +2.5 % over loads-then-MFMAs)
