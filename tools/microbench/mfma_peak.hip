@@ -1,0 +1,165 @@
+// Sustained MFMA rate of the chip under its own clock management: bare loops of
+// v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16 on register operands, and the chain
+// kernel's instruction mix (one ds_read_b128 per two 16x16x32 MFMAs), on random or zero data.
+// Prints TFLOP/s per variant; the number to hold a real kernel's rate against when the nominal
+// peak (2.4 GHz x 1024 SIMDs) is out of reach because the chip lowers its clock under MFMA load.
+//   hipcc -O3 --offload-arch=gfx950 mfma_peak.hip -o mfma_peak && ./mfma_peak [ms_per_variant]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// 18 accumulators of 16x16 (the chain kernel's 9 pixel tiles x 2 channel tiles)
+template <bool LDS>
+__global__ __launch_bounds__(512, 2) void loop16(const bf16x8* __restrict__ src, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  bf16x8 w[2], a[9];
+  for (int i = 0; i < 2; ++i) w[i] = src[(tid * 11 + i) & 4095];
+  for (int i = 0; i < 9; ++i) a[i] = src[(tid * 11 + 2 + i) & 4095];
+  if (LDS) {
+    for (int i = tid; i < 9 * 1024 * 8 / 16; i += 512) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+    __syncthreads();
+  }
+  f32x4 acc[9][2];
+  for (int m = 0; m < 9; ++m) for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  int off = lane * 16;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 9; ++m) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[n], a[m], acc[m][n], 0, 0, 0);
+      if (LDS) a[m] = *reinterpret_cast<const bf16x8*>(lds + off + m * 1024 + (it & 7) * 9216);
+    }
+    if (LDS) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  }
+  float s = 0;
+  for (int m = 0; m < 9; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+// the chain kernel's full k-step: 18 MFMAs, 9 LDS reads one step ahead, 2 weight-fragment buffer
+// loads two steps ahead (fragments stream from a 1.2 MB array as one layer's do)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 2) void loop16w(const bf16x8* __restrict__ src, const void* wts, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 9 * 1024 * 8 / 16; i += 512) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wts), 0, 74 * 16384, 0x00020000);
+  const int wl = wave * 2048 + lane * 16;
+  auto wf = [&](int off, int nt) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wl + nt * 1024, off, 0)); };
+  bf16x8 a[9], wq[2][2];
+  for (int i = 0; i < 9; ++i) a[i] = *reinterpret_cast<const bf16x8*>(lds + lane * 16 + i * 1024);
+  for (int p = 0; p < 2; ++p) for (int n = 0; n < 2; ++n) wq[p][n] = wf(p * 16384, n);
+  f32x4 acc[9][2];
+  for (int m = 0; m < 9; ++m) for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  const int off = lane * 16;
+  for (int it = 0; it < iters; it += 8) {
+    int wo = 2 * 16384 + (it % 64) * 16384;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bf16x8 w2[2];
+      for (int n = 0; n < 2; ++n) w2[n] = wf(wo, n);
+      wo += 16384;
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][n], a[m], acc[m][n], 0, 0, 0);
+        a[m] = *reinterpret_cast<const bf16x8*>(lds + off + m * 1024 + k * 9216);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      for (int n = 0; n < 2; ++n) { wq[0][n] = wq[1][n]; wq[1][n] = w2[n]; }
+    }
+  }
+  float s = 0;
+  for (int m = 0; m < 9; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+// 4 accumulators of 32x32 (same accumulator registers per wave as 16 of 16x16)
+__global__ __launch_bounds__(512, 2) void loop32(const bf16x8* __restrict__ src, float* out, int iters) {
+  const int tid = threadIdx.x;
+  bf16x8 w[2], a[2];
+  for (int i = 0; i < 2; ++i) { w[i] = src[(tid * 7 + i) & 4095]; a[i] = src[(tid * 7 + 2 + i) & 4095]; }
+  f32x16 acc[2][2];
+  for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int j = 0; j < 16; ++j) acc[m][n][j] = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[n], a[m], acc[m][n], 0, 0, 0);
+  }
+  float s = 0;
+  for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int j = 0; j < 16; ++j) s += acc[m][n][j];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+int main(int argc, char** argv) {
+  const double target_ms = argc > 1 ? atof(argv[1]) : 300.0;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  bf16x8* src; float* out;
+  CHECK(hipMalloc(&src, 4096 * 16));
+  CHECK(hipMalloc(&out, (size_t)cus * 512 * 4));
+  void* wts;
+  CHECK(hipMalloc(&wts, 74 * 16384));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16w), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int zero = 0; zero < 2; ++zero) {
+    std::vector<unsigned short> h(4096 * 8);
+    srand(1);
+    for (auto& v : h) v = zero ? 0 : (unsigned short)(0x3c00 + (rand() & 0x83ff));  // |x| in [0.5, 2) with random sign / mantissa
+    CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    for (int i = 0; i < 74 * 16384; i += 4096 * 16) CHECK(hipMemcpy((char*)wts + i, h.data(), 74 * 16384 - i < 4096 * 16 ? 74 * 16384 - i : 4096 * 16, hipMemcpyHostToDevice));
+    for (int variant = 0; variant < 4; ++variant) {
+      const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : 18.0 * 2 * 16 * 16 * 32;  // per wave
+      auto launch = [&](int iters) {
+        if (variant == 0) hipLaunchKernelGGL(loop16<false>, dim3(cus), dim3(512), 0, 0, src, out, iters);
+        if (variant == 1) hipLaunchKernelGGL(loop16<true>, dim3(cus), dim3(512), 9 * 1024 * 8, 0, src, out, iters);
+        if (variant == 2) hipLaunchKernelGGL(loop32, dim3(cus), dim3(512), 0, 0, src, out, iters);
+        if (variant == 3) hipLaunchKernelGGL(loop16w, dim3(cus), dim3(512), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
+      };
+      int iters = 20000;
+      launch(iters);
+      CHECK(hipDeviceSynchronize());
+      float ms = 0;
+      for (int rep = 0; rep < 2; ++rep) {  // second pass sized to target_ms so the clock has settled
+        CHECK(hipEventRecord(e0));
+        launch(iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep == 0) iters = (int)(iters * target_ms / ms);
+      }
+      const double tf = flop_per_iter * iters * 8.0 * cus / (ms * 1e-3) / 1e12;
+      const char* names[4] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
+                              "16x16x32 + LDS reads + 2 weight loads per 18"};
+      printf("%-46s %-6s data: %7.1f TFLOP/s  (%.1f ms, %d CUs x 8 waves)\n", names[variant], zero ? "zero" : "random", tf, ms, cus);
+    }
+  }
+  return 0;
+}
