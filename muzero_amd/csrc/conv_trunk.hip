@@ -294,10 +294,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
   typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
   const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   const int vb0 = lds_base + kq * (8 * kPlaneB) + r16 * 16;
+  const int vz0 = lds_base + kq * (8 * kPlaneB) + kPix * 16;
   auto tap_addresses = [&](int tap, int buf_off, int (&addr)[kMT]) {
     const int dy = tap / 3, dx = tap - dy * 3;
-    const int t = vb0 + (buf_off + ((dy - 1) * kSide + (dx - 1)) * 16);
-    const int z = vb0 + (buf_off + kPix * 16);
+    const int shift = (dy - 1) * kSide + (dx - 1);
+    const int t = vb0 + (buf_off + shift * 16);
+    // the zero pixel a redirected lane reads sits in the bank its own pixel would have used, so
+    // that redirected and ordinary lanes of a read never collide
+    const int z = vz0 + buf_off + ((r16 + shift) & 15) * 16;
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
       unsigned long long bad = dx == 0 ? edge_lanes(mt, 0) : dx == 2 ? edge_lanes(mt, kSide - 1) : 0ull;

@@ -41,3 +41,6 @@ img = st[:, :, 1:, 0, 0] - st[:, :, :-1, 4, 3]
 print("between images (store + load):", img.mean().round(0))
 print("whole image:", (st[:, :, :, 4, 3] - st[:, :, :, 0, 0]).mean().round(0), " first stamp to last:", st.max() - st.min())
 print("wave0 vs wave5 main loop", loop[:, 0].mean().round(0), loop[:, 1].mean().round(0))
+for w, name in enumerate(("wave 0", "wave 5")):
+    print(name, "by layer: main loop", loop[:, w].mean((0, 1)).round(0), "epilogue", epi[:, w].mean((0, 1)).round(0),
+          "barrier wait", bar[:, w].mean((0, 1)).round(0))

@@ -3,7 +3,7 @@
 // kernel's instruction mix (one ds_read_b128 per two 16x16x32 MFMAs), on random or zero data.
 // Prints TFLOP/s per variant; the number to hold a real kernel's rate against when the nominal
 // peak (2.4 GHz x 1024 SIMDs) is out of reach because the chip lowers its clock under MFMA load.
-//   hipcc -O3 --offload-arch=gfx950 mfma_peak.hip -o mfma_peak && ./mfma_peak [ms_per_variant]
+//   hipcc -O3 --offload-arch=gfx950 mfma_peak.hip -o mfma_peak && ./mfma_peak [ms_per_variant [threads_per_CU]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(512, 2) void loop16(const bf16x8* __restrict__ src,
   for (int i = 0; i < 2; ++i) w[i] = src[(tid * 11 + i) & 4095];
   for (int i = 0; i < 9; ++i) a[i] = src[(tid * 11 + 2 + i) & 4095];
   if (LDS) {
-    for (int i = tid; i < 9 * 1024 * 8 / 16; i += 512) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+    for (int i = tid; i < 9 * 1024 * 8 / 16; i += blockDim.x) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
     __syncthreads();
   }
   f32x4 acc[9][2];
@@ -56,7 +56,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512, 2) void loop16w(const bf16x8* __restrict__ src, const void* wts, float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < 9 * 1024 * 8 / 16; i += 512) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+  for (int i = tid; i < 9 * 1024 * 8 / 16; i += blockDim.x) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
   __syncthreads();
   __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wts), 0, 74 * 16384, 0x00020000);
   const int wl = wave * 2048 + lane * 16;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void loop32(const bf16x8* __restrict__ src,
 
 int main(int argc, char** argv) {
   const double target_ms = argc > 1 ? atof(argv[1]) : 300.0;
+  const int threads = argc > 2 ? atoi(argv[2]) : 512;  // 512: two wavefronts per SIMD, 256: one
   hipDeviceProp_t prop;
   CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
@@ -138,10 +139,10 @@ int main(int argc, char** argv) {
     for (int variant = 0; variant < 4; ++variant) {
       const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : 18.0 * 2 * 16 * 16 * 32;  // per wave
       auto launch = [&](int iters) {
-        if (variant == 0) hipLaunchKernelGGL(loop16<false>, dim3(cus), dim3(512), 0, 0, src, out, iters);
-        if (variant == 1) hipLaunchKernelGGL(loop16<true>, dim3(cus), dim3(512), 9 * 1024 * 8, 0, src, out, iters);
-        if (variant == 2) hipLaunchKernelGGL(loop32, dim3(cus), dim3(512), 0, 0, src, out, iters);
-        if (variant == 3) hipLaunchKernelGGL(loop16w, dim3(cus), dim3(512), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
+        if (variant == 0) hipLaunchKernelGGL(loop16<false>, dim3(cus), dim3(threads), 0, 0, src, out, iters);
+        if (variant == 1) hipLaunchKernelGGL(loop16<true>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, out, iters);
+        if (variant == 2) hipLaunchKernelGGL(loop32, dim3(cus), dim3(threads), 0, 0, src, out, iters);
+        if (variant == 3) hipLaunchKernelGGL(loop16w, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
       };
       int iters = 20000;
       launch(iters);
@@ -155,10 +156,10 @@ int main(int argc, char** argv) {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep == 0) iters = (int)(iters * target_ms / ms);
       }
-      const double tf = flop_per_iter * iters * 8.0 * cus / (ms * 1e-3) / 1e12;
+      const double tf = flop_per_iter * iters * (threads / 64.0) * cus / (ms * 1e-3) / 1e12;
       const char* names[4] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
                               "16x16x32 + LDS reads + 2 weight loads per 18"};
-      printf("%-46s %-6s data: %7.1f TFLOP/s  (%.1f ms, %d CUs x 8 waves)\n", names[variant], zero ? "zero" : "random", tf, ms, cus);
+      printf("%-46s %-6s data: %7.1f TFLOP/s  (%.1f ms, %d CUs x %d waves)\n", names[variant], zero ? "zero" : "random", tf, ms, cus, threads / 64);
     }
   }
   return 0;
