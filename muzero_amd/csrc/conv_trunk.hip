@@ -12,6 +12,8 @@
 // bank group because half of the group reads the next channel chunk).  Pixels
 // 144..159 of every plane are zero: a lane whose tap falls outside the image reads
 // the zero pixel that shares a bank group with the pixel it would have read.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -392,6 +394,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+      // this layer's bias and the next layer's weight descriptor are fetched now, not when the
+      // epilogue needs them
+      float4 bv[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt)
+        bv[nt] = *reinterpret_cast<const float4*>(a.bias[l] + (wave * WN + nt) * 16 + kq * 4);
+      const __amdgpu_buffer_rsrc_t wr_next = wdesc(last ? l : l + 1);
+
       int aaddr[kMT];
       tap_addresses(0, sbuf_off, aaddr);
       bf16x8 af[kMT];
@@ -443,10 +453,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       touched ^= pf0 ^ pf1;
       MZ_STAMP(1);  // main loop done
       // next layer's first weight fragments travel while this layer's epilogue runs
-      const float* bias = a.bias[l];
       const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
       if (!last) {
-        wr = wdesc(l + 1);
+        wr = wr_next;
 #pragma unroll
         for (int p = 0; p < PF; ++p)
 #pragma unroll
@@ -455,41 +464,45 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       }
 
       // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
-      // mt*16 + r16; the result goes to the destination buffer in the planar layout
+      // mt*16 + r16; the result goes to the destination buffer in the planar layout.  Only the
+      // last layer sums its outputs over the pixels (the heads' input).
+      auto epilogue = [&](auto with_mean) {
+        constexpr bool kMean = decltype(with_mean)::value;
 #pragma unroll
-      for (int nt = 0; nt < WN; ++nt) {
-        const int cbase = (wave * WN + nt) * 16 + kq * 4;
-        const float4 bv = *reinterpret_cast<const float4*>(bias + cbase);
-        char* plane = dbuf + plane_of(cbase >> 3) * kPlaneB + (cbase & 4) * 2;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int nt = 0; nt < WN; ++nt) {
+          const int cbase = (wave * WN + nt) * 16 + kq * 4;
+          char* plane = dbuf + plane_of(cbase >> 3) * kPlaneB + (cbase & 4) * 2;
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < kMT; ++mt) {
-          char* slot = plane + (mt * 16 + r16) * 16;
-          float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
-          float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
-          if (res) {
-            const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
-            v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+          for (int mt = 0; mt < kMT; ++mt) {
+            char* slot = plane + (mt * 16 + r16) * 16;
+            float v0 = acc[mt][nt][0] + bv[nt].x, v1 = acc[mt][nt][1] + bv[nt].y;
+            float v2 = acc[mt][nt][2] + bv[nt].z, v3 = acc[mt][nt][3] + bv[nt].w;
+            if (res) {
+              const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
+              v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
+            }
+            if (relu) {
+              v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+            }
+            if (kMean) { s0 += v0; s1 += v1; s2 += v2; s3 += v3; }
+            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            *reinterpret_cast<bf16x4*>(slot) = ov;
           }
-          if (relu) {
-            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          if (kMean) {
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+              s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
+            }
+            if (r16 == 0) {
+              const float inv = 1.0f / (float)kPix;
+              *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
+                  make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
+            }
           }
-          s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-          const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-          *reinterpret_cast<bf16x4*>(slot) = ov;
         }
-        if (last && a.mean_out) {
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
-          }
-          if (r16 == 0) {
-            const float inv = 1.0f / (float)kPix;
-            *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
-                make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
-          }
-        }
-      }
+      };
+      if (last && a.mean_out) epilogue(std::true_type{}); else epilogue(std::false_type{});
       MZ_STAMP(2);  // epilogue done
       __syncthreads();
       MZ_STAMP(3);  // barrier passed
