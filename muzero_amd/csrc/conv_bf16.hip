@@ -147,26 +147,35 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // weight fragments: [k-step][n-tile][lane][8]; this wave's n-tiles are wave*WN .. +WN
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) + (long)wave * WN * 64 + lane;
-  constexpr int WSTEP = C::NTILES * 64;  // bf16x8 elements per k-step
+  // weight fragments: [k-step][n-tile][lane][8]; this wave's n-tiles are wave*WN .. +WN.  They
+  // come by buffer loads: base in a scalar descriptor, k-step offset in a scalar register, the
+  // lane's own offset fixed - no vector address arithmetic (reads past the array return zero)
+  constexpr int WSTEP = C::NTILES * 1024;  // bytes per k-step
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(a.wpk), 0, (C::KSTEPS + 2) * WSTEP, 0x00020000);
+  const int wlane = wave * (WN * 1024) + lane * 16;
+  auto wfrag = [&](int step_off, int nt) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane + nt * 1024, step_off, 0));
+  };
   bf16x8 w0[WN], w1[WN];
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
-    w0[nt] = wp[nt * 64];
-    if constexpr (C::PF == 2) w1[nt] = wp[WSTEP + nt * 64];
+    w0[nt] = wfrag(0, nt);
+    if constexpr (C::PF == 2) w1[nt] = wfrag(WSTEP, nt);
   }
-  wp += C::PF * WSTEP;
+  int wp = C::PF * WSTEP;
 
   // LDS byte address of this lane's pixel (tap 0, first k-step) in each 16-pixel tile; every
   // other tap / k-step is a compile-time offset from it, so it rides in the ds_read immediate
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   int abase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int m = mt * 16 + r16;
     if (m >= C::M) m = C::M - 1;  // padding rows recompute the last pixel; never stored
     const int py = m / C::TW, px = m % C::TW;
-    abase[mt] = (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16;
+    abase[mt] = lds_base + (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16;
   }
   constexpr int NS = 9 * KC;  // k-steps per channel chunk
   auto step_offset = [](int st) {
@@ -179,28 +188,24 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
     if constexpr (ROT) stage_input_rot<C>(lds, src, iy0, ix0, tid);
     else stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
     __syncthreads();
-    // software pipeline: the LDS operand of step st+1 is read while step st's MFMAs run
-    bf16x8 afA[MT], afB[MT];
+    // software pipeline: a pixel tile's operand register is refilled with step st+1's operand
+    // right after step st's MFMAs have read it
+    bf16x8 af[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(lds + abase[mt]);
+    for (int mt = 0; mt < MT; ++mt) af[mt] = *(lds_frag_ptr)(abase[mt]);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      bf16x8(&cur)[MT] = (st & 1) ? afB : afA;
-      bf16x8(&nxt)[MT] = (st & 1) ? afA : afB;
       bf16x8 w2[WN];
 #pragma unroll
-      for (int nt = 0; nt < WN; ++nt) w2[nt] = wp[nt * 64];  // PF k-steps ahead (the buffer is padded)
+      for (int nt = 0; nt < WN; ++nt) w2[nt] = wfrag(wp, nt);  // PF k-steps ahead
       wp += WSTEP;
-      if (st + 1 < NS) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          nxt[mt] = *reinterpret_cast<const bf16x8*>(lds + abase[mt] + step_offset(st + 1));
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        if (st + 1 < NS) af[mt] = *(lds_frag_ptr)(abase[mt] + step_offset(st + 1));
+      }
       __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
