@@ -72,8 +72,12 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
                                             int tid) {
   constexpr int UPP = C::CINC / 8;  // 16-byte units per pixel
   constexpr int UNITS = C::IH * C::IW * UPP;
-#pragma unroll 4
-  for (int u = tid; u < UNITS; u += C::THREADS) {
+  // every load of the window is in flight before the first LDS write waits for one
+  constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int u = tid + i * C::THREADS;
+    if (u >= UNITS) break;
     const int pix = u / UPP, cu = u % UPP;
     const int py = pix / C::IW, px = pix % C::IW;
     const int iy = iy0 + py, ix = ix0 + px;
