@@ -128,6 +128,29 @@ def test_chain_kernel_any_batch(B):
     assert torch.equal(out, t[2])      # same arithmetic in both kernels: bit-identical
 
 
+def test_chain_kernel_repeats_bit_for_bit():
+    """Twenty launches of the dynamics-shaped chain at the benchmark's batch size on the same input:
+    every result equals the first (no race between wavefronts, no read of stale LDS)."""
+    from muzero_amd import _lib, mfma
+    B, n = 1024, 5
+    g = torch.Generator().manual_seed(7)
+    w = [mfma.pack_weights(torch.randn(256, 256, 3, 3, generator=g) / 48.0, 256).cuda() for _ in range(n)]
+    bias = [(torch.randn(256, generator=g) * 0.1).cuda() for _ in range(n)]
+    x = torch.randn(B, 12, 12, 256, generator=g).to(torch.bfloat16).cuda()
+    arr = (_lib.ChainLayer * n)()
+    for i in range(n):
+        arr[i] = _lib.ChainLayer(w[i].data_ptr(), bias[i].data_ptr(), 1, 1 if (i % 2 == 0 and i > 0) else 0)
+    outs = [torch.empty_like(x) for _ in range(20)]
+    means = [torch.empty(B, 256, device="cuda") for _ in range(20)]
+    for o, m in zip(outs, means):
+        _lib.call("mz_conv_chain_bf16", _lib.ptr(x), None, 0, arr, n, _lib.ptr(o), None, None, _lib.ptr(m), B,
+                  _lib.current_stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[0].float()).all() and outs[0].float().abs().max() > 0
+    for o, m in zip(outs[1:], means[1:]):
+        assert torch.equal(o, outs[0]) and torch.equal(m, means[0])
+
+
 def test_rotating_observation_equals_the_stacked_one():
     """The rotating, tiled form of the frame stack (3 values rewritten per pixel and move) is the
     stacked observation with its channels permuted, bit for bit, after a reset and after any number
