@@ -12,6 +12,7 @@
 // bank group because half of the group reads the next channel chunk).  Pixels
 // 144..159 of every plane are zero: a lane whose tap falls outside the image reads
 // the zero pixel that shares a bank group with the pixel it would have read.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -134,6 +135,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   int aaddr[kMT];
   tap_addresses(0, aaddr);
   __syncthreads();
+  if (a.residual) {  // the accumulation starts from the residual (as in the chain kernels)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+      const int cbase = (wave * WN + nt) * 16 + kq * 4;
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(ldsB + (mt * 16 + r16) * kRowB + cbase * 2);
+        acc[mt][nt] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      }
+    }
+  }
   bf16x8 afA[kMT], afB[kMT];
 #pragma unroll
   for (int mt = 0; mt < kMT; ++mt) afA[mt] = *reinterpret_cast<const bf16x8*>(lds + aaddr[mt]);
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
     for (int mt = 0; mt < kMT; ++mt) aaddr[mt] = anext[mt];
   }
 
-  // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16); add bias and
-  // the residual (from LDS), apply ReLU, round to bf16 and park the result in LDS region B
+  // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16); add bias,
+  // apply ReLU, round to bf16 and park the result in LDS region B
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int cbase = (wave * WN + nt) * 16 + kq * 4;
@@ -190,10 +202,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
       char* slot = ldsB + (mt * 16 + r16) * kRowB + cbase * 2;
       float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
       float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
-      if (a.residual) {
-        const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
-        v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
-      }
       if (a.relu) {
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       }
@@ -393,6 +401,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((a.res_mask >> l) & 1u) {  // the accumulation starts from the residual: what the destination buffer holds
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          const int cbase = (wave * WN + nt) * 16 + kq * 4;
+          const char* plane = dbuf + plane_of(cbase >> 3) * kPlaneB + (cbase & 4) * 2;
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(plane + (mt * 16 + r16) * 16);
+            acc[mt][nt] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+          }
+        }
+      }
 
       // this layer's bias and the next layer's weight descriptor are fetched now, not when the
       // epilogue needs them
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       touched ^= pf0 ^ pf1;
       MZ_STAMP(1);  // main loop done
       // next layer's first weight fragments travel while this layer's epilogue runs
-      const bool relu = (a.relu_mask >> l) & 1u, res = (a.res_mask >> l) & 1u;
+      const bool relu = (a.relu_mask >> l) & 1u;
       if (!last) {
         wr = wr_next;
 #pragma unroll
@@ -478,10 +498,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
             char* slot = plane + (mt * 16 + r16) * 16;
             float v0 = acc[mt][nt][0] + bv[nt].x, v1 = acc[mt][nt][1] + bv[nt].y;
             float v2 = acc[mt][nt][2] + bv[nt].z, v3 = acc[mt][nt][3] + bv[nt].w;
-            if (res) {
-              const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
-              v0 += (float)r[0]; v1 += (float)r[1]; v2 += (float)r[2]; v3 += (float)r[3];
-            }
             if (relu) {
               v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
@@ -520,6 +536,278 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       }
     }
     __syncthreads();  // the next image overwrites buffer 0
+  }
+  if (a.B < 0) a.mean_out[tid] = __int_as_float(touched);  // never true: B > 0 is checked by the host
+}
+
+// ---------------------------------------------------------------------------
+// The same chain for TWO images per workgroup pass.  A weight fragment then feeds
+// 18 MFMAs instead of 9: half the weight-fragment traffic (L2 -> registers) per
+// MFMA, which is what the chip's clock management rewards - this loop sustains
+// ~11 % more than the one-image loop on random data at the same MFMA count.
+//
+// Both images live in LDS once (no second buffer): 64 planes, image i's plane p at
+// (2p + i) * kPlaneB, each layer written over its own input.  A layer is: main loop
+// (reads everything) - barrier - epilogue (each wavefront overwrites the 32 channels
+// it owns, both images) - barrier.  What the single-image kernel finds in its second
+// buffer - the input of a residual block, to be added to the block's second
+// convolution - is picked up here just before it is overwritten: the epilogue of
+// the block's first convolution loads it into the accumulators, which the second
+// convolution then starts from (instead of from zero).
+// Per k-step a wavefront runs two half-steps of 18 MFMAs with the same two weight
+// fragments, image 0 then image 1; a pixel tile's operand register is refilled
+// right after its MFMAs with the other image's operand (same k-step after image 0,
+// next k-step after image 1), so 9 operand registers serve both images with the
+// same 18-MFMA lead as in the single-image loop.
+// ---------------------------------------------------------------------------
+template <int PF>
+__global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NW = 8, WN = 2;
+  constexpr int WSTEP = 16 * 1024;       // bytes of weight fragments per k-step
+  constexpr int PSTRIDE = 2 * kPlaneB;   // LDS bytes between consecutive planes of one image
+  constexpr int KOFF = PSTRIDE;          // ... between consecutive 32-channel k-steps
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  // operand addresses as in conv_chain_kernel (image 0; image 1 is kPlaneB further)
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int vb0 = lds_base + kq * (8 * PSTRIDE) + r16 * 16;
+  const int vz0 = lds_base + kq * (8 * PSTRIDE) + kPix * 16;
+  auto tap_addresses = [&](int tap, int (&addr)[kMT]) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int shift = (dy - 1) * kSide + (dx - 1);
+    const int t = vb0 + shift * 16;
+    const int z = vz0 + ((r16 + shift) & 15) * 16;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      unsigned long long bad = dx == 0 ? edge_lanes(mt, 0) : dx == 2 ? edge_lanes(mt, kSide - 1) : 0ull;
+      if (mt == 0 && dy == 0) bad |= 0x0FFF0FFF0FFF0FFFull;
+      addr[mt] = __builtin_amdgcn_inverse_ballot_w64(bad) ? z : t + mt * 256;
+    }
+  };
+  auto plane_of = [](int q) { return (q & 3) * 8 + (q >> 2); };  // channel chunk q -> plane of its image
+
+  {  // zero pixels of all 64 planes (never written afterwards)
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64)
+      *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
+  }
+
+  const int wlane = wave * (WN * 1024) + lane * 16;
+  auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
+  };
+  auto wdesc = [&](int l) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+  };
+  auto image_base = [&](int bb) {
+    const long img = a.in_slot ? (long)a.in_slot[bb] * a.slot_stride + bb : bb;
+    return a.in + img * (long)(kPix * kCh);
+  };
+  const int pl = lane & 15, qq = lane >> 4;
+
+  int touched = 0;  // sink of the next-pair prefetch loads (keeps them alive; never stored)
+  for (int b0 = blockIdx.x; b0 < a.B; b0 += 2 * gridDim.x) {
+    // the pass's images; a missing second image repeats the first and is never stored
+    const bool two = b0 + (int)gridDim.x < a.B;
+    const int bimg[2] = {b0, two ? b0 + (int)gridDim.x : b0};
+    // next pass's images, pulled towards L2 during the last layer (one 4-byte load per 128-byte line)
+    const char* nsrc[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) {
+      const int nb = b0 + (2 + i) * (int)gridDim.x;
+      if (nb < a.B) nsrc[i] = reinterpret_cast<const char*>(image_base(nb));
+    }
+
+    __amdgpu_buffer_rsrc_t wr = wdesc(0);
+    int wp = 0;
+    bf16x8 wq[PF][WN];  // wq[0] feeds the current k-step, wq[PF-1] was requested last
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
+    wp = PF * WSTEP;
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // images -> LDS (planar); 72 blocks of (16 pixels x 4 channel chunks) each
+      const __bf16* src = image_base(bimg[i]);
+      const float* av = a.avec ? a.avec + (long)a.actions[bimg[i]] * kCh : nullptr;
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
+        if (av) {
+          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+          v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
+          v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
+          v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
+          v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+        }
+        *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + pix * 16) = v;
+      }
+    }
+    __syncthreads();
+
+    f32x4 acc[2][kMT][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[i][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+      const bool last = l == a.n_layers - 1;
+#ifdef MZ_CHAIN_STAMPS
+      const bool stamp = (blockIdx.x == 7 || blockIdx.x == 130) && lane == 0 && (wave == 0 || wave == 5) && l < 8;
+      const int sidx = ((((blockIdx.x == 130) * 2 + (wave == 5)) * 4 + ((b0 / (2 * (int)gridDim.x)) & 3)) * 8 + l) * 4;
+#endif
+      MZ_STAMP(0);  // layer start
+      float4 bv[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt)
+        bv[nt] = *reinterpret_cast<const float4*>(a.bias[l] + (wave * WN + nt) * 16 + kq * 4);
+      const __amdgpu_buffer_rsrc_t wr_next = wdesc(last ? l : l + 1);
+
+      int aaddr[kMT];
+      tap_addresses(0, aaddr);
+      bf16x8 af[kMT];
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) af[mt] = *(lds_frag_ptr)(aaddr[mt]);
+
+      int pf = 0;
+      if (last) {  // 2 x 576 lines of 128 bytes, 512 threads
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (nsrc[i]) {
+            pf ^= *reinterpret_cast<const int*>(nsrc[i] + tid * 128);
+            if (tid < kPix * kCh * 2 / 128 - 64 * NW) pf ^= *reinterpret_cast<const int*>(nsrc[i] + (64 * NW + tid) * 128);
+          }
+      }
+
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int kc = 0; kc < kKC; ++kc) {
+          bf16x8 w2[WN];
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) w2[nt] = wfrag(wr, wp, nt);
+          wp += WSTEP;
+          // image 0; each operand register is refilled with image 1's operand of this k-step
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[0][mt][nt], 0, 0, 0);
+            af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kPlaneB + kc * KOFF));
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
+#pragma unroll
+          for (int i = 0; i < kMT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, aaddr);  // the next step is the next tap's first
+          // image 1; refill with image 0's operand of the next k-step
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[1][mt][nt], 0, 0, 0);
+            af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
+          }
+#pragma unroll
+          for (int i = 0; i < kMT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+#pragma unroll
+            for (int p = 0; p + 1 < PF; ++p) wq[p][nt] = wq[p + 1][nt];
+            wq[PF - 1][nt] = w2[nt];
+          }
+        }
+      }
+      touched ^= pf;
+      MZ_STAMP(1);  // main loop done
+
+      __syncthreads();  // every wavefront has read the layer's input: it may be overwritten
+      MZ_STAMP(2);  // everyone has finished reading
+      const bool relu = (a.relu_mask >> l) & 1u;
+      const bool keep_input = !last && ((a.res_mask >> (l + 1)) & 1u);  // the next layer adds this layer's input
+      if (!last) {  // next layer's first weight fragments travel while the epilogue runs
+        wr = wr_next;
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
+        wp = PF * WSTEP;
+      }
+      // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
+      // mt*16 + r16 of both images; results replace the layer's input in place
+      const float floor_v = relu ? 0.f : -__builtin_inff();
+      const int keep_bits = keep_input ? -1 : 0;
+      const bool want_mean = last && a.mean_out;
+      // one straight path for every layer kind (selects, not branches, around the accumulators)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          const int cbase = (wave * WN + nt) * 16 + kq * 4;
+          char* plane = lds + (plane_of(cbase >> 3) * 2 + i) * kPlaneB + (cbase & 4) * 2;
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+            char* slot = plane + (mt * 16 + r16) * 16;
+            const float v0 = fmaxf(acc[i][mt][nt][0] + bv[nt].x, floor_v), v1 = fmaxf(acc[i][mt][nt][1] + bv[nt].y, floor_v);
+            const float v2 = fmaxf(acc[i][mt][nt][2] + bv[nt].z, floor_v), v3 = fmaxf(acc[i][mt][nt][3] + bv[nt].w, floor_v);
+            // the next layer's starting value: this layer's input where the next layer adds it, else zero
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
+            acc[i][mt][nt] = f32x4{__int_as_float(__float_as_int((float)r[0]) & keep_bits),
+                                   __int_as_float(__float_as_int((float)r[1]) & keep_bits),
+                                   __int_as_float(__float_as_int((float)r[2]) & keep_bits),
+                                   __int_as_float(__float_as_int((float)r[3]) & keep_bits)};
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            *reinterpret_cast<bf16x4*>(slot) = ov;
+          }
+          if (want_mean) {  // only the last layer's outputs are averaged over the pixels (the heads' input)
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+              s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
+            }
+            if (r16 == 0 && (i == 0 || two)) {
+              const float inv = 1.0f / (float)kPix;
+              *reinterpret_cast<float4*>(a.mean_out + (long)bimg[i] * kCh + cbase) =
+                  make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
+            }
+          }
+        }
+      __syncthreads();
+      MZ_STAMP(3);  // outputs in place
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // results -> global, same (16 pixels x 4 chunks) blocks as the load
+      if (i == 1 && !two) break;
+      __bf16* dst = a.out + (long)bimg[i] * (kPix * kCh);
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        *reinterpret_cast<bf16x8*>(dst + pix * kCh + q * 8) =
+            *reinterpret_cast<const bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + pix * 16);
+      }
+    }
+    __syncthreads();  // the next images overwrite these
   }
   if (a.B < 0) a.mean_out[tid] = __int_as_float(touched);  // never true: B > 0 is checked by the host
 }
@@ -569,12 +857,23 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
     if (layers[l].relu) a.relu_mask |= 1u << l;
     if (layers[l].add_residual) a.res_mask |= 1u << l;
   }
+  constexpr int lds = 2 * kLdsBytes;
+  const int n_cu = mz::compute_units();
+  // one persistent workgroup per CU (all of its LDS); with at least two images per CU the
+  // workgroups take them two at a time
+  static const bool no_pairs = getenv("MZ_CHAIN_NO_PAIRS") != nullptr;  // kernel comparisons
+  if (B >= 2 * n_cu && !no_pairs) {
+    static bool configured2[mz::kMaxDevices] = {false};
+    auto kern2 = conv_chain_pair_kernel<MZ_CHAIN_PF>;
+    if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), lds, configured2, "conv_chain_pair"))
+      return rc;
+    hipLaunchKernelGGL(kern2, dim3(n_cu), dim3(512), lds, stream, a);
+    return mz::check_launch("mz_conv_chain_bf16");
+  }
   static bool configured[mz::kMaxDevices] = {false};
   auto kern = conv_chain_kernel<MZ_CHAIN_NW, MZ_CHAIN_PF>;
-  constexpr int lds = 2 * kLdsBytes;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain")) return rc;
-  const int n_cu = mz::compute_units();
-  const int grid = B < n_cu ? B : n_cu;  // one persistent workgroup per CU (all of its LDS)
+  const int grid = B < n_cu ? B : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MZ_CHAIN_NW), lds, stream, a);
   return mz::check_launch("mz_conv_chain_bf16");
 }

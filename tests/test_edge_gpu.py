@@ -128,6 +128,38 @@ def test_chain_kernel_any_batch(B):
     assert torch.equal(out, t[2])      # same arithmetic in both kernels: bit-identical
 
 
+@pytest.mark.parametrize("B", [512, 600, 1024])
+def test_chain_kernel_two_images_per_pass_equals_one_per_pass(B):
+    """From two images per compute unit on, workgroups take the images two at a time (shared weight
+    fragments, layers written over their own input): the same arithmetic in the same order, so the
+    result equals, bit for bit, that of the same images sent in batches small enough for the
+    one-image kernel - with and without residual layers, with a single image left over (B = 600),
+    spatial means included."""
+    from muzero_amd import _lib, mfma
+    n = 5
+    g = torch.Generator().manual_seed(B)
+    w = [mfma.pack_weights(torch.randn(256, 256, 3, 3, generator=g) / 48.0, 256).cuda() for _ in range(n)]
+    bias = [(torch.randn(256, generator=g) * 0.1).cuda() for _ in range(n)]
+    x = torch.randn(B, 12, 12, 256, generator=g).to(torch.bfloat16).cuda()
+
+    def chain(inp, res_flags):
+        arr = (_lib.ChainLayer * n)()
+        for i in range(n):
+            arr[i] = _lib.ChainLayer(w[i].data_ptr(), bias[i].data_ptr(), 1 if i != 1 else 0, res_flags[i])
+        out, mean = torch.empty_like(inp), torch.empty(inp.shape[0], 256, device="cuda")
+        _lib.call("mz_conv_chain_bf16", _lib.ptr(inp), None, 0, arr, n, _lib.ptr(out), None, None, _lib.ptr(mean),
+                  inp.shape[0], _lib.current_stream())
+        torch.cuda.synchronize()
+        return out, mean
+
+    for flags in ([0] * n, [0, 0, 1, 0, 1]):
+        out, mean = chain(x, flags)
+        parts = [chain(x[i:i + 200].contiguous(), flags) for i in range(0, B, 200)]
+        assert torch.equal(out, torch.cat([p[0] for p in parts]))
+        assert torch.equal(mean, torch.cat([p[1] for p in parts]))
+        assert out.float().abs().max() > 0
+
+
 def test_chain_kernel_repeats_bit_for_bit():
     """Twenty launches of the dynamics-shaped chain at the benchmark's batch size on the same input:
     every result equals the first (no race between wavefronts, no read of stale LDS)."""
