@@ -754,7 +754,9 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
       // mt*16 + r16 of both images; results replace the layer's input in place
       const float floor_v = relu ? 0.f : -__builtin_inff();
-      const int keep_bits = keep_input ? -1 : 0;
+      // bf16 pair -> two floats or two zeros, one instruction each: the odd element is the dword's
+      // upper half (AND), the even one its lower half moved up (byte permute; selector 0x0c = zero)
+      const unsigned keep_hi = keep_input ? 0xffff0000u : 0u, keep_lo = keep_input ? 0x01000c0cu : 0x0c0c0c0cu;
       const bool want_mean = last && a.mean_out;
       // one straight path for every layer kind (selects, not branches, around the accumulators)
 #pragma unroll
@@ -770,11 +772,9 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
             const float v0 = fmaxf(acc[i][mt][nt][0] + bv[nt].x, floor_v), v1 = fmaxf(acc[i][mt][nt][1] + bv[nt].y, floor_v);
             const float v2 = fmaxf(acc[i][mt][nt][2] + bv[nt].z, floor_v), v3 = fmaxf(acc[i][mt][nt][3] + bv[nt].w, floor_v);
             // the next layer's starting value: this layer's input where the next layer adds it, else zero
-            const bf16x4 r = *reinterpret_cast<const bf16x4*>(slot);
-            acc[i][mt][nt] = f32x4{__int_as_float(__float_as_int((float)r[0]) & keep_bits),
-                                   __int_as_float(__float_as_int((float)r[1]) & keep_bits),
-                                   __int_as_float(__float_as_int((float)r[2]) & keep_bits),
-                                   __int_as_float(__float_as_int((float)r[3]) & keep_bits)};
+            const uint2 r = *reinterpret_cast<const uint2*>(slot);
+            acc[i][mt][nt] = f32x4{__uint_as_float(__builtin_amdgcn_perm(r.x, r.x, keep_lo)), __uint_as_float(r.x & keep_hi),
+                                   __uint_as_float(__builtin_amdgcn_perm(r.y, r.y, keep_lo)), __uint_as_float(r.y & keep_hi)};
             s0 += v0; s1 += v1; s2 += v2; s3 += v3;
             const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
             *reinterpret_cast<bf16x4*>(slot) = ov;
