@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Where the cycles of the convolution chain go: run the dynamics-shaped chain (5 layers, B=1024)
-on a diagnostic build of the library whose kernel records the shader clock at the phase
-boundaries of every layer, and print per-layer averages.
+"""Where the cycles of the convolution chain go: run the dynamics-shaped chain (5 layers, B=2048:
+four passes of two images per workgroup; with MZ_CHAIN_NO_PAIRS=1 eight passes of one image) on a
+diagnostic build of the library whose kernels record the shader clock at the phase boundaries of
+every layer, and print per-layer averages.  Phases of the one-image kernel: main loop, epilogue,
+barrier.  Of the two-image kernel: main loop, wait until every wavefront has finished reading
+(printed as "epilogue"), epilogue + barrier (printed as "barrier wait").
 
     make -C muzero_amd/csrc stamps            # builds muzero_amd/csrc/libmuzero_amd_stamps.so
     MUZERO_AMD_LIB=$PWD/muzero_amd/csrc/libmuzero_amd_stamps.so python tools/chain_phase_stamps.py
@@ -16,7 +19,7 @@ import torch  # noqa: E402
 
 from muzero_amd import _lib, mfma  # noqa: E402
 
-B, n_layers = 1024, 5
+B, n_layers = 2048, 5
 keep = []
 arr = (_lib.ChainLayer * n_layers)()
 for l in range(n_layers):
