@@ -630,6 +630,11 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
     wp = PF * WSTEP;
 
+    // (the lane's block coordinates pass through an empty asm so that the addresses derived from
+    // them are computed here and now: hoisted to the top of the kernel they would sit in
+    // registers, or rather in scratch memory, through every layer of every pass)
+    int plv = pl, qqv = qq;
+    asm volatile("" : "+v"(plv), "+v"(qqv));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // images -> LDS (planar); 72 blocks of (16 pixels x 4 channel chunks) each
       const __bf16* src = image_base(bimg[i]);
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
 #pragma unroll
       for (int j = 0; j < 72 / NW; ++j) {
         const int it = wave + NW * j;
-        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        const int pix = (it >> 3) * 16 + plv, q = (it & 7) * 4 + qqv;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
         if (av) {
           const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
@@ -668,10 +673,6 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       const int sidx = ((((blockIdx.x == 130) * 2 + (wave == 5)) * 4 + ((b0 / (2 * (int)gridDim.x)) & 3)) * 8 + l) * 4;
 #endif
       MZ_STAMP(0);  // layer start
-      float4 bv[WN];
-#pragma unroll
-      for (int nt = 0; nt < WN; ++nt)
-        bv[nt] = *reinterpret_cast<const float4*>(a.bias[l] + (wave * WN + nt) * 16 + kq * 4);
       const __amdgpu_buffer_rsrc_t wr_next = wdesc(last ? l : l + 1);
 
       int aaddr[kMT];
@@ -739,6 +740,10 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       touched ^= pf;
       MZ_STAMP(1);  // main loop done
 
+      float4 bv[WN];  // requested before the barrier, needed after it
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt)
+        bv[nt] = *reinterpret_cast<const float4*>(a.bias[l] + (wave * WN + nt) * 16 + kq * 4);
       __syncthreads();  // every wavefront has read the layer's input: it may be overwritten
       MZ_STAMP(2);  // everyone has finished reading
       const bool relu = (a.relu_mask >> l) & 1u;
@@ -795,6 +800,8 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       MZ_STAMP(3);  // outputs in place
     }
 
+    plv = pl, qqv = qq;
+    asm volatile("" : "+v"(plv), "+v"(qqv));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // results -> global, same (16 pixels x 4 chunks) blocks as the load
       if (i == 1 && !two) break;
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
 #pragma unroll
       for (int j = 0; j < 72 / NW; ++j) {
         const int it = wave + NW * j;
-        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        const int pix = (it >> 3) * 16 + plv, q = (it & 7) * 4 + qqv;
         *reinterpret_cast<bf16x8*>(dst + pix * kCh + q * 8) =
             *reinterpret_cast<const bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + pix * 16);
       }

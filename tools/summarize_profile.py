@@ -28,7 +28,7 @@ bench = json.loads(open(os.path.join(out, "bench_stats.json")).read().strip().sp
 
 # dynamics launches of the chain kernel = the short ones (5 layers); the representation tail has 18
 trace = list(csv.DictReader(open(one("stats/**/*kernel_trace.csv"))))
-chain = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if "conv_chain_kernel" in r["Kernel_Name"]]
+chain = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if "conv_chain_" in r["Kernel_Name"]]
 cut = 2 * statistics.median(chain)
 dyn = [d for d in chain if d < cut]
 tail = [d for d in chain if d >= cut]
@@ -40,7 +40,7 @@ lines = [f"# {tag}: kernel statistics", "",
 for r in rows[:16]:
     name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     lines.append(f"| `{name[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
-lines += ["", f"`conv_chain_kernel`, dynamics launches (5 layers): {len(dyn)} launches, mean {statistics.mean(dyn) / 1e3:.1f} us, "
+lines += ["", f"chain kernel (`conv_chain_pair_kernel` from two images per CU on, else `conv_chain_kernel`), dynamics launches (5 layers): {len(dyn)} launches, mean {statistics.mean(dyn) / 1e3:.1f} us, "
           f"median {statistics.median(dyn) / 1e3:.1f} us; representation-tail launches (18 layers): {len(tail)}, "
           f"mean {statistics.mean(tail) / 1e3:.1f} us." if tail else "",
           f"bench.py's HIP-event timing of the dynamics launches in the same run: {bench['roofline']['launch_us']:.1f} us "
@@ -52,7 +52,7 @@ def pmc_mean(kind, counter):
     path = one(f"{kind}/**/*counter_collection.csv")
     vals = {}
     for r in csv.DictReader(open(path)):
-        if "conv_chain_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if "conv_chain_" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.setdefault(r["Dispatch_Id"], 0.0)
             vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
     v = sorted(vals.values())
@@ -66,7 +66,7 @@ try:
     B = bench["config"]["games_per_gpu"]
     fetch_b, write_b = fetch_kib * 1024 * 2, write_kib * 1024     # gfx950: 128-B read requests are tallied at 64 B
     algo = B * 2 * 144 * 256 * 2 + 5 * 9 * 256 * 256 * 2 + B * 256 * 4
-    traffic = {"kernel": "conv_chain_kernel<8,2> (dynamics, 5 layers)", "games_per_gpu": B,
+    traffic = {"kernel": "conv_chain_pair_kernel (dynamics, 5 layers)", "games_per_gpu": B,
                "hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
                "algorithmic_bytes_per_launch": algo, "launches_averaged": [n_f, n_w],
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 1 "
