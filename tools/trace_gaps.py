@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 kernel trace (csv): per-kernel totals and the idle time between
-consecutive kernels.  usage: trace_gaps.py <kernel_trace.csv> [skip_fraction]"""
+"""Summarise a rocprofv3 kernel trace (csv) of bench.py move by move: a move starts at each
+obs_slot_write launch; for every move the span, the busy time, the idle share and the largest
+kinds of gap between consecutive kernels, then per-kernel totals over the steady-state moves
+(those without host-side pauses: idle below 5 %).   usage: trace_gaps.py <kernel_trace.csv>"""
 import csv
 import sys
 from collections import defaultdict
@@ -8,24 +10,40 @@ from collections import defaultdict
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
-rows = rows[int(len(rows) * skip):]          # steady state only
-busy = sum(e - s for s, e, _ in rows)
-span = rows[-1][1] - rows[0][0]
-gaps = defaultdict(lambda: [0, 0])
-for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
-    g = gaps[(n0, n1)]
-    g[0] += 1
-    g[1] += max(0, s1 - e0)
-print(f"kernels {len(rows)}  span {span/1e6:.2f} ms  busy {busy/1e6:.2f} ms  idle {100*(span-busy)/span:.1f}%")
-per = defaultdict(lambda: [0, 0])
-for s, e, n in rows:
-    per[n][0] += 1
-    per[n][1] += e - s
-for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:12]:
-    print(f"  {t/1e6:8.2f} ms  {c:5d} x {t/c/1e3:8.1f} us  {n}")
-print("largest gaps (after -> before):")
-for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:8]:
-    print(f"  {t/1e6:8.2f} ms  {c:5d} x {t/c/1e3:6.1f} us  {a[:28]} -> {b[:28]}")
+import re
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return re.split(r"[<(]", n, 1)[0].split("::")[-1][:40]
+starts = [i for i, r in enumerate(rows) if "obs_slot_write" in r[2]]
+moves = [rows[a:b] for a, b in zip(starts, starts[1:]) if b - a > 20]
+print(f"{len(rows)} kernels, {len(moves)} moves")
+steady = []
+for k, seg in enumerate(moves):
+    span = seg[-1][1] - seg[0][0]
+    busy = sum(e - s for s, e, _ in seg)
+    gaps = defaultdict(lambda: [0, 0])
+    for (s0, e0, n0), (s1, e1, n1) in zip(seg, seg[1:]):
+        g = gaps[(short(n0), short(n1))]
+        g[0] += 1
+        g[1] += max(0, s1 - e0)
+    idle = 100 * (span - busy) / span
+    top = sorted(gaps.items(), key=lambda kv: -kv[1][1])[:2]
+    print(f"move {k}: {len(seg)} kernels, span {span / 1e6:.2f} ms, busy {busy / 1e6:.2f} ms, idle {idle:.1f} %; largest gaps: "
+          + "; ".join(f"{a} -> {b}: {c} x {t / c / 1e3:.1f} us" for (a, b), (c, t) in top))
+    if idle < 5:
+        steady.append(seg)
+if steady:
+    per = defaultdict(lambda: [0, 0])
+    total = 0
+    for seg in steady:
+        total += seg[-1][1] - seg[0][0]
+        for s, e, n in seg:
+            per[short(n)][0] += 1
+            per[short(n)][1] += e - s
+    print(f"steady-state moves: {len(steady)}, {total / len(steady) / 1e6:.2f} ms per move; per move and kernel:")
+    for n, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:10]:
+        print(f"  {t / len(steady) / 1e6:7.3f} ms  {c // len(steady):4d} x {t / c / 1e3:8.1f} us  {n}")
