@@ -257,6 +257,9 @@ __host__ __device__ constexpr unsigned long long edge_lanes(int mt, int x_edge) 
 #ifndef MZ_CHAIN_NW
 #define MZ_CHAIN_NW 8
 #endif
+#ifndef MZ_PAIR_PF
+#define MZ_PAIR_PF 1  // weight queue depth of the two-image kernel: its k-steps are twice as long, one step ahead is the same lead
+#endif
 // -DMZ_CHAIN_STAMPS builds a diagnostic variant (tools/chain_phase_stamps.py): two workgroups
 // record the shader clock at the phase boundaries of every layer.
 #ifdef MZ_CHAIN_STAMPS
@@ -871,7 +874,7 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   static const bool no_pairs = getenv("MZ_CHAIN_NO_PAIRS") != nullptr;  // kernel comparisons
   if (B >= 2 * n_cu && !no_pairs) {
     static bool configured2[mz::kMaxDevices] = {false};
-    auto kern2 = conv_chain_pair_kernel<MZ_CHAIN_PF>;
+    auto kern2 = conv_chain_pair_kernel<MZ_PAIR_PF>;
     if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), lds, configured2, "conv_chain_pair"))
       return rc;
     hipLaunchKernelGGL(kern2, dim3(n_cu), dim3(512), lds, stream, a);
