@@ -208,7 +208,7 @@ def main():
         if prof and prof.get("games_per_gpu") == B:
             traffic = prof.get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "mfma",
-                           "kernel": ("conv_chain_pair_kernel" if B >= 2 * torch.cuda.get_device_properties(0).multi_processor_count
+                           "kernel": ("conv_chain_pair_kernel" if B > torch.cuda.get_device_properties(0).multi_processor_count
                                       else "conv_chain_kernel") + f": dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
                            "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                            "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,

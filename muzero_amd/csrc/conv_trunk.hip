@@ -869,15 +869,16 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   }
   constexpr int lds = 2 * kLdsBytes;
   const int n_cu = mz::compute_units();
-  // one persistent workgroup per CU (all of its LDS); with at least two images per CU the
-  // workgroups take them two at a time
+  // one persistent workgroup per CU (all of its LDS); with more images than CUs the workgroups
+  // take them two at a time (a pass of two costs ~1.85 passes of one)
   static const bool no_pairs = getenv("MZ_CHAIN_NO_PAIRS") != nullptr;  // kernel comparisons
-  if (B >= 2 * n_cu && !no_pairs) {
+  if (B > n_cu && !no_pairs) {
     static bool configured2[mz::kMaxDevices] = {false};
     auto kern2 = conv_chain_pair_kernel<MZ_PAIR_PF>;
     if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), lds, configured2, "conv_chain_pair"))
       return rc;
-    hipLaunchKernelGGL(kern2, dim3(n_cu), dim3(512), lds, stream, a);
+    const int pairs = (B + 1) / 2;
+    hipLaunchKernelGGL(kern2, dim3(pairs < n_cu ? pairs : n_cu), dim3(512), lds, stream, a);
     return mz::check_launch("mz_conv_chain_bf16");
   }
   static bool configured[mz::kMaxDevices] = {false};

@@ -128,9 +128,9 @@ def test_chain_kernel_any_batch(B):
     assert torch.equal(out, t[2])      # same arithmetic in both kernels: bit-identical
 
 
-@pytest.mark.parametrize("B", [512, 600, 1024])
+@pytest.mark.parametrize("B", [257, 301, 512, 600, 1024])
 def test_chain_kernel_two_images_per_pass_equals_one_per_pass(B):
-    """From two images per compute unit on, workgroups take the images two at a time (shared weight
+    """With more images than compute units, workgroups take the images two at a time (shared weight
     fragments, layers written over their own input): the same arithmetic in the same order, so the
     result equals, bit for bit, that of the same images sent in batches small enough for the
     one-image kernel - with and without residual layers, with a single image left over (B = 600),
@@ -154,7 +154,7 @@ def test_chain_kernel_two_images_per_pass_equals_one_per_pass(B):
 
     for flags in ([0] * n, [0, 0, 1, 0, 1]):
         out, mean = chain(x, flags)
-        parts = [chain(x[i:i + 200].contiguous(), flags) for i in range(0, B, 200)]
+        parts = [chain(x[i:i + 200].contiguous(), flags) for i in range(0, B, 200)]      # 200 < CUs: one image per pass
         assert torch.equal(out, torch.cat([p[0] for p in parts]))
         assert torch.equal(mean, torch.cat([p[1] for p in parts]))
         assert out.float().abs().max() > 0

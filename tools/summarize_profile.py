@@ -40,7 +40,7 @@ lines = [f"# {tag}: kernel statistics", "",
 for r in rows[:16]:
     name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
     lines.append(f"| `{name[:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
-lines += ["", f"chain kernel (`conv_chain_pair_kernel` from two images per CU on, else `conv_chain_kernel`), dynamics launches (5 layers): {len(dyn)} launches, mean {statistics.mean(dyn) / 1e3:.1f} us, "
+lines += ["", f"chain kernel (`conv_chain_pair_kernel` with more images than CUs, else `conv_chain_kernel`), dynamics launches (5 layers): {len(dyn)} launches, mean {statistics.mean(dyn) / 1e3:.1f} us, "
           f"median {statistics.median(dyn) / 1e3:.1f} us; representation-tail launches (18 layers): {len(tail)}, "
           f"mean {statistics.mean(tail) / 1e3:.1f} us." if tail else "",
           f"bench.py's HIP-event timing of the dynamics launches in the same run: {bench['roofline']['launch_us']:.1f} us "
