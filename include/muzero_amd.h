@@ -112,6 +112,16 @@ int mz_tree_expand_backup_select(void* ws, const mz_tree_layout* L, const float*
                                  const float* reward, int32_t wave, double gamma, const double* pbc_table,
                                  const double* sqrt_table, int32_t table_len, mz_stream_t stream);
 
+/* MCTS.ucb_score (model.py:499-513) for n independent edges, with the arithmetic the descent uses (the same
+ * device function): scores[i] from the parent's visit count, the child's visit count and value sum, and the
+ * MinMaxStats bounds (minimum > maximum = nothing recorded yet).  Exactly one of prior32 (float priors: float32
+ * product and sum, returned widened to double) and prior64 (noised-root priors: double throughout) is given.
+ * The caller guarantees 0 <= parent_visits[i] < table_len (device data). */
+int mz_ucb_score(const int32_t* parent_visits, const int32_t* child_visits, const double* value_sum,
+                 const double* minimum, const double* maximum, const float* prior32, const double* prior64,
+                 const double* pbc_table, const double* sqrt_table, int32_t table_len, int32_t n, double* scores,
+                 mz_stream_t stream);
+
 /* Search result per game (model.py:472-480 and Node.value, model.py:386-389):
  * visits int32 [B][A], root_value double [B], probs double [B][A]
  * (uniform when no child was visited). Any output may be NULL. */
@@ -296,6 +306,29 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
                      const int64_t* value_off, int32_t n_games, int32_t A, const int32_t* q_game,
                      const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
                      double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream);
+
+/* ReplayBuffer.sample_batch's draw (model.py:580-588) on device-resident priorities: double prio [n], one per
+ * stored position, oldest game first.  u: double [batch], the [0,1) draws np.random.choice would consume.
+ * Outputs: flat int32 [batch] = #(cdf <= u) with cdf the normalised cumulative sum of prio / sum(prio)
+ * (np.random.choice's inversion; uniform over the positions when every priority is zero, model.py:581-583);
+ * weights double [batch] = (n * prob[flat]) ** -beta divided by their maximum (model.py:587-588); and, when
+ * game_start (int64 [n_games + 1], first flat index of every game, game_start[n_games] = n) is given, the game
+ * and in-game position each index falls into (the scan of model.py:592-596).  The cumulative sums are formed in
+ * a fixed two-level order rather than left to right, so they equal the reference's to rounding and an index can
+ * differ only for a draw within a few ulp of a boundary of the distribution.
+ * workspace: caller-owned device memory of at least mz_replay_workspace_bytes(n) bytes, 8-byte aligned (chunk
+ * sums and their scan); its contents need not be preserved between calls. */
+int64_t mz_replay_workspace_bytes(int64_t n);
+int mz_replay_sample(const double* prio, int64_t n, const double* u, int32_t batch, double beta,
+                     const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game, int32_t* pos,
+                     double* weights, void* workspace, int64_t workspace_bytes, mz_stream_t stream);
+
+/* ReplayBuffer.update_priorities (model.py:612-614): prio[flat[i]] = (values[i] + 1e-6) ** alpha for i in list
+ * order (of several entries naming one slot the last wins).  flat holds FLAT position indices as
+ * mz_replay_sample returns them (the reference passes in-game offsets here, model.py:595 / :607, and so writes
+ * other slots than it sampled; that is not reproduced).  Entries outside [0, n) are ignored. */
+int mz_replay_update(double* prio, int64_t n, const int32_t* flat, const double* values, int32_t m, double alpha,
+                     mz_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "mz_tree_expand_backup": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P]),
     "mz_tree_expand_backup_select": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, C.c_int32, C.c_double, _P, _P,
                                                C.c_int32, _P]),
+    "mz_ucb_score": (C.c_int, [_P] * 9 + [C.c_int32, C.c_int32, _P, _P]),
     "mz_tree_readout": (C.c_int, [_P, C.POINTER(TreeLayout), _P, _P, _P, _P]),
     "mz_select_action": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, _P, _P]),
     "mz_conv3x3_f32": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
@@ -59,6 +60,10 @@ _SIGNATURES = {
     "mz_obs_slot_write": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                     _P]),
     "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "mz_replay_workspace_bytes": (C.c_int64, [C.c_int64]),
+    "mz_replay_sample": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_double, _P, C.c_int32, _P, _P, _P, _P, _P,
+                                   C.c_int64, _P]),
+    "mz_replay_update": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int32, C.c_double, _P]),
 }
 
 _lib = None

@@ -117,6 +117,35 @@ __global__ __launch_bounds__(kBlock) void root_init_kernel(TreeView t, const flo
   }
 }
 
+// ------------------------------------------------------------------ score
+// ucb_score (model.py:499-513) with MinMaxStats.normalize (model.py:364-370) and Node.value
+// (model.py:386-389) for one edge, in the reference's own mix of float32 and float64: the
+// exploration factor and the normalised value are doubles; with a float32 prior (every node but a
+// noised root) the product and the sum are float32 (NumPy >= 2 scalar promotion), with a float64
+// prior (noised root) they stay double.  pbc = log((N + c_base + 1) / c_base) + c_init and
+// sqrt_n = sqrt(N) of the parent's visit count N come from host tables.
+__device__ __forceinline__ double edge_score(double pbc, double sqrt_n, int n, double w, double lo, double hi,
+                                             bool wide, float prior32, double prior64) {
+  const double c = pbc * (sqrt_n / (double)(n + 1));
+  double vs = 0.0;
+  if (n > 0) vs = hi > lo ? (w / (double)n - lo) / (hi - lo) : 0.5;
+  if (wide) return c * prior64 + vs;
+  const float ps = (float)c * prior32;
+  return (double)(ps + (float)vs);  // float32 sum, widened only to compare
+}
+
+__global__ void ucb_score_kernel(const int* __restrict__ parent_visits, const int* __restrict__ child_visits,
+                                 const double* __restrict__ value_sum, const double* __restrict__ lo,
+                                 const double* __restrict__ hi, const float* __restrict__ prior32,
+                                 const double* __restrict__ prior64, const double* __restrict__ pbc,
+                                 const double* __restrict__ sq, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int pn = parent_visits[i];
+  out[i] = edge_score(pbc[pn], sq[pn], child_visits[i], value_sum[i], lo[i], hi[i], prior64 != nullptr,
+                      prior32 ? prior32[i] : 0.f, prior64 ? prior64[i] : 0.0);
+}
+
 // ------------------------------------------------------------------ select
 __device__ __forceinline__ void select_game(const TreeView& t, const double* __restrict__ pbc,
                                             const double* __restrict__ sq, int table_len, int b, int lane) {
@@ -138,15 +167,9 @@ __device__ __forceinline__ void select_game(const TreeView& t, const double* __r
       kid = t.child[row + lane];
       const double w = t.value_sum[row + lane];
       const int pn = parent_n < table_len ? parent_n : table_len - 1;  // too-short tables are reported below
-      const double c = pbc[pn] * (sq[pn] / (double)(n + 1));
-      double vs = 0.0;
-      if (n > 0) vs = hi > lo ? (w / (double)n - lo) / (hi - lo) : 0.5;
-      if (root64 && node == 0) {
-        score = c * t.root_prior64[(size_t)b * A + lane] + vs;
-      } else {
-        const float ps = (float)c * t.prior[row + lane];
-        score = (double)(ps + (float)vs);  // float32 sum, widened only to compare
-      }
+      const bool wide = root64 && node == 0;
+      score = edge_score(pbc[pn], sq[pn], n, w, lo, hi, wide, t.prior[row + lane],
+                         wide ? t.root_prior64[(size_t)b * A + lane] : 0.0);
       if (!(score > ninf)) score = ninf;  // NaN and -inf never beat the initial -inf
     }
     // wavefront argmax, strict '>' in action order == lowest action among equals: the maximum,
@@ -500,6 +523,19 @@ int mz_select_action(const int32_t* visits, int32_t B, int32_t A, double tempera
   hipLaunchKernelGGL(select_action_kernel, dim3((B + 63) / 64), dim3(64), 0, mz::as_stream(stream), visits, B,
                      A, temperature, u, actions);
   return mz::check_launch("mz_select_action");
+}
+
+int mz_ucb_score(const int32_t* parent_visits, const int32_t* child_visits, const double* value_sum,
+                 const double* minimum, const double* maximum, const float* prior32, const double* prior64,
+                 const double* pbc_table, const double* sqrt_table, int32_t table_len, int32_t n, double* scores,
+                 mz_stream_t stream) {
+  MZ_REQUIRE(parent_visits && child_visits && value_sum && minimum && maximum && pbc_table && sqrt_table && scores,
+             "mz_ucb_score: null argument");
+  MZ_REQUIRE((prior32 != nullptr) != (prior64 != nullptr), "mz_ucb_score: exactly one of prior32 / prior64");
+  MZ_REQUIRE(n > 0 && table_len > 0, "mz_ucb_score: bad sizes");
+  hipLaunchKernelGGL(ucb_score_kernel, dim3((n + 255) / 256), dim3(256), 0, mz::as_stream(stream), parent_visits,
+                     child_visits, value_sum, minimum, maximum, prior32, prior64, pbc_table, sqrt_table, n, scores);
+  return mz::check_launch("mz_ucb_score");
 }
 
 }  // extern "C"

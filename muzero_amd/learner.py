@@ -137,22 +137,6 @@ class TrainableNetwork(nn.Module):
 
 
 # --------------------------------------------------------------------------- loss
-def _support_ce_torch(logits, targets, support_size: int):
-    """The reference's own sequence of torch ops (model.py:84-86, :112-140)."""
-    t = torch.sign(targets) * (torch.sqrt(torch.abs(targets) + 1) - 1 + 0.001 * targets)
-    t = torch.clamp(t, -support_size, support_size)
-    fl = t.floor()
-    up_p = t - fl
-    lo_p = 1 - up_p
-    sup = torch.zeros(t.size(0), 2 * support_size + 1, device=t.device)
-    lo = (fl + support_size).long()
-    up = (lo + 1).clamp_(0, 2 * support_size)
-    lo = lo.clamp_(0, 2 * support_size)
-    sup.scatter_(1, lo.unsqueeze(1), lo_p.unsqueeze(1))
-    sup.scatter_(1, up.unsqueeze(1), up_p.unsqueeze(1))
-    return -(sup * F.log_softmax(logits, dim=1)).sum(1)
-
-
 class _SupportCEHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, support_size):
@@ -171,14 +155,18 @@ class _SupportCEHip(torch.autograd.Function):
         return dlog * grad_out.unsqueeze(1), None, None
 
 
-def support_ce_loss(logits, targets, support_size: int, impl: str = "hip"):
-    """-(two_hot(transform(target)) * log_softmax(logits)).sum(1).  impl "hip": fused kernel
-    (device tensors only); "torch": the reference's op sequence."""
-    if impl == "hip":
-        if not logits.is_cuda:
-            raise _lib.MuZeroAmdError("support_ce_loss(impl='hip') needs device tensors; pass impl='torch' on the CPU")
-        return _SupportCEHip.apply(logits, targets, support_size)
-    return _support_ce_torch(logits, targets, support_size)
+def support_ce_loss(logits, targets, support_size: int, impl="hip"):
+    """-(two_hot(transform(target)) * log_softmax(logits)).sum(1) (model.py:132-140).  impl "hip": the fused
+    kernel (device tensors only; there is no CPU implementation in this package).  A callable
+    ``impl(logits, targets, support_size)`` is used instead when given: the tests run the learner's host logic
+    on the CPU with the reference's op sequence that way."""
+    if callable(impl):
+        return impl(logits, targets, support_size)
+    if impl != "hip":
+        raise ValueError("impl must be 'hip' or a callable")
+    if not logits.is_cuda:
+        raise _lib.MuZeroAmdError("support_ce_loss: the HIP kernel needs device tensors")
+    return _SupportCEHip.apply(logits, targets, support_size)
 
 
 # --------------------------------------------------------------------------- episodes and targets
@@ -337,6 +325,80 @@ def batched_targets(games: Sequence[GameHistory], queries: Sequence[Tuple[int, i
     return store.targets(q[:, 0], q[:, 1], K, td_steps)
 
 
+class DevicePriorities:
+    """The replay window's priorities on the device, one float64 per stored position, oldest game first,
+    plus the first flat index of every game.  Draws (model.py:580-596) and priority updates
+    (model.py:612-614) run as kernels (``mz_replay_sample``, ``mz_replay_update``), so a training batch
+    is chosen and re-prioritised without the priorities crossing PCIe."""
+
+    def __init__(self, device="cuda", capacity: int = 1 << 16):
+        self.device = torch.device(device)
+        self._prio = torch.empty(max(capacity, 1), dtype=torch.float64, device=self.device)
+        self._head = self._tail = 0
+        self._lengths: List[int] = []
+        self._starts = None          # device int64 [n_games + 1], refreshed lazily
+        self._ws = None
+
+    def __len__(self):
+        return self._tail - self._head
+
+    @property
+    def values(self) -> torch.Tensor:
+        """A view of the live priorities (writes go through)."""
+        return self._prio[self._head:self._tail]
+
+    def append_game(self, priorities) -> None:
+        v = torch.as_tensor(np.asarray(priorities, np.float64))
+        n = v.numel()
+        if self._tail + n > self._prio.numel():        # compact, then grow if still short
+            live = self._prio[self._head:self._tail]
+            fresh = torch.empty(max(self._prio.numel(), 2 * (live.numel() + n)), dtype=torch.float64,
+                                device=self.device)
+            fresh[:live.numel()] = live
+            self._prio, self._head, self._tail = fresh, 0, live.numel()
+        self._prio[self._tail:self._tail + n] = v.to(self.device)
+        self._tail += n
+        self._lengths.append(n)
+        self._starts = None
+
+    def pop_front(self) -> None:
+        self._head += self._lengths.pop(0)
+        self._starts = None
+
+    def sample(self, uniforms, beta: float):
+        """uniforms: [batch] float64 draws in [0, 1) (array or device tensor).  -> device tensors
+        (flat int32, game int32, position int32, weights float64)."""
+        n = len(self)
+        if n == 0:
+            raise IndexError("sampling from an empty replay window")
+        u = torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous()
+        batch = u.numel()
+        if self._starts is None:
+            self._starts = torch.tensor(np.concatenate([[0], np.cumsum(self._lengths)]), dtype=torch.int64,
+                                        device=self.device)
+        need = _lib.lib().mz_replay_workspace_bytes(n)
+        if self._ws is None or self._ws.numel() * 8 < need:
+            self._ws = torch.empty(max(need // 8 * 2, 64), dtype=torch.float64, device=self.device)
+        flat = torch.empty(batch, dtype=torch.int32, device=self.device)
+        game, pos = torch.empty_like(flat), torch.empty_like(flat)
+        w = torch.empty(batch, dtype=torch.float64, device=self.device)
+        prio = self.values
+        _lib.call("mz_replay_sample", _lib.ptr(prio), n, _lib.ptr(u), batch, float(beta), _lib.ptr(self._starts),
+                  len(self._lengths), _lib.ptr(flat), _lib.ptr(game), _lib.ptr(pos), _lib.ptr(w), _lib.ptr(self._ws),
+                  self._ws.numel() * 8, _lib.current_stream())
+        return flat, game, pos, w
+
+    def update(self, flat, values, alpha: float) -> None:
+        f = torch.as_tensor(flat).to(self.device, torch.int32).contiguous()
+        v = torch.as_tensor(values, dtype=torch.float64).to(self.device).contiguous()
+        if f.numel() != v.numel():
+            raise ValueError("one priority per index")
+        if f.numel() == 0:
+            return
+        _lib.call("mz_replay_update", _lib.ptr(self.values), len(self), _lib.ptr(f), _lib.ptr(v), f.numel(),
+                  float(alpha), _lib.current_stream())
+
+
 class ReplayBuffer:
     """Prioritised replay over positions (model.py:549-618), host side.  One departure from
     the reference, on purpose: ``sample_batch`` returns the FLAT position index of every
@@ -344,7 +406,8 @@ class ReplayBuffer:
     the index after it was reduced to an in-game offset, model.py:595 / :607, and so updates
     the wrong slots)."""
 
-    def __init__(self, config, episode_store: Optional[EpisodeStore] = None):
+    def __init__(self, config, episode_store: Optional[EpisodeStore] = None,
+                 device_priorities: Optional[DevicePriorities] = None):
         self.window_size = config.replay_buffer_size
         self.batch_size = config.batch_size
         self.alpha = config.priority_alpha
@@ -353,6 +416,8 @@ class ReplayBuffer:
         self._prio = np.empty(1024, np.float64)   # one priority per position, live part [_head, _tail)
         self._head = self._tail = 0
         self.store = episode_store           # device mirror for batched targets (optional)
+        self.device_priorities = device_priorities   # device mirror of the priorities (optional): when given,
+        #                                              sample_positions_device / update_priorities_device use it
 
     def __len__(self):
         return len(self.buffer)
@@ -389,11 +454,15 @@ class ReplayBuffer:
         self._append(np.asarray(priorities, np.float64))
         if self.store is not None:
             self.store.add_game(game)
+        if self.device_priorities is not None:
+            self.device_priorities.append_game(priorities)
         while len(self.buffer) > self.window_size:
             old = self.buffer.pop(0)
             self._head += len(old.rewards)
             if self.store is not None:
                 self.store.pop_front()
+            if self.device_priorities is not None:
+                self.device_priorities.pop_front()
 
     def sample_positions(self, uniforms: Optional[np.ndarray] = None):
         """-> (game index, in-game position, flat index) arrays and importance weights.
@@ -416,7 +485,26 @@ class ReplayBuffer:
 
     def update_priorities(self, flat_indices, priorities) -> None:
         idx = np.asarray(flat_indices, np.int64)
-        self.priorities[idx] = (np.asarray(priorities, np.float64) + 1e-6) ** self.alpha
+        pr = np.asarray(priorities, np.float64)
+        for i, v in zip(idx, pr):                      # list order: the last of several entries for a slot wins
+            self.priorities[i] = (v + 1e-6) ** self.alpha
+        if self.device_priorities is not None:
+            self.device_priorities.update(idx, pr, self.alpha)
+
+    def sample_positions_device(self, uniforms=None):
+        """``sample_positions`` drawn by the device kernel from the device copy of the priorities:
+        -> device tensors (game, position, flat index, weights)."""
+        if self.device_priorities is None:
+            raise ValueError("this buffer was built without device_priorities")
+        u = np.random.random_sample(self.batch_size) if uniforms is None else uniforms
+        flat, game, pos, w = self.device_priorities.sample(u, self.beta)
+        return game, pos, flat, w
+
+    def update_priorities_device(self, flat_indices, priorities) -> None:
+        """New priorities for sampled positions from device tensors (e.g. the per-sample losses of the
+        update that consumed them); the host copy of the priorities is refreshed from the device."""
+        self.device_priorities.update(flat_indices, priorities, self.alpha)
+        self.priorities[:] = self.device_priorities.values.cpu().numpy()
 
 
 def compute_priorities(game: GameHistory, td_steps: int) -> np.ndarray:
@@ -440,7 +528,7 @@ def unroll_actions(action_lists, K: int) -> np.ndarray:
 
 
 class Learner:
-    def __init__(self, config, device="cuda", state_dict=None, loss_impl: Optional[str] = None,
+    def __init__(self, config, device="cuda", state_dict=None, loss_impl=None,
                  precision: str = "fp32", autotune: bool = True, data_parallel: bool = False):
         """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
         convolutions and linear layers under bfloat16 autocast with float32 master weights,
@@ -456,7 +544,7 @@ class Learner:
         self.data_parallel = data_parallel   # every rank trains on its own batch; gradients are averaged
         self.precision = precision
         self.device = torch.device(device)
-        self.loss_impl = loss_impl or ("hip" if self.device.type == "cuda" else "torch")
+        self.loss_impl = loss_impl or "hip"    # or a callable, see support_ce_loss
         self.network = TrainableNetwork(config).to(self.device)      # stays in training mode (train.py:155)
         if state_dict is not None:
             self.network.load_state_dict(state_dict)
@@ -474,7 +562,7 @@ class Learner:
         checkpoint.write(path, self.training_step, self.network, self.optimizer, self.scheduler, self.config)
 
     @classmethod
-    def from_checkpoint(cls, path: str, device="cuda", loss_impl: Optional[str] = None) -> "Learner":
+    def from_checkpoint(cls, path: str, device="cuda", loss_impl=None) -> "Learner":
         """Resume from a checkpoint written by the reference or by ``save_checkpoint``:
         weights, BatchNorm statistics, momentum buffers, learning-rate schedule and step."""
         ck = checkpoint.read(path)

@@ -31,6 +31,11 @@ import model as M  # noqa: E402  (the reference)
 
 from oracle import nets as onets  # noqa: E402  (only for randomize_bn / digest helpers)
 
+# ucb_score mixes np.float32 priors with Python floats (model.py:505-513): under NumPy >= 2 (NEP 50) the
+# product stays float32, under NumPy 1.x it is promoted to float64 and near-tie argmaxes can differ.  The
+# fixtures (and the device kernels checked against them) are the NumPy >= 2 behaviour.
+assert int(np.__version__.split(".")[0]) >= 2, "generate the fixtures under NumPy >= 2"
+
 HASH_MOD = 2147483647
 T_ROWS = 1024
 SMALL_S = 10

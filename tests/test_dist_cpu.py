@@ -46,6 +46,7 @@ from muzero_amd import dist as mzdist
 from muzero_amd.config import MuZeroConfig
 from muzero_amd.learner import Learner
 from muzero_amd.network import init_state_dict
+from oracle.loss import support_ce
 
 rank, world, local = mzdist.init_from_env("gloo")
 cfg = MuZeroConfig(); cfg.num_channels = 16; cfg.downsample_steps = [(8, 1), (16, 1)]
@@ -64,12 +65,12 @@ def batch(r):
 # what the averaged gradient must be: the mean of the two ranks' own gradients
 grads = []
 for r in range(world):
-    solo = Learner(cfg, device="cpu", state_dict=sd, loss_impl="torch")
+    solo = Learner(cfg, device="cpu", state_dict=sd, loss_impl=support_ce)
     solo.losses_from_tensors(*batch(r))[3].mean().backward()
     grads.append([p.grad.clone() for p in solo.network.parameters()])
 want = [sum(g) / world for g in zip(*grads)]
 
-dp = Learner(cfg, device="cpu", state_dict=sd, loss_impl="torch", data_parallel=True)
+dp = Learner(cfg, device="cpu", state_dict=sd, loss_impl=support_ce, data_parallel=True)
 dp.losses_from_tensors(*batch(rank))[3].mean().backward()
 mzdist.average_gradients(dp.network.parameters())
 for p, w in zip(dp.network.parameters(), want):

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests.helpers import load
+from oracle.loss import support_ce
 
 from muzero_amd.config import MuZeroConfig
 from muzero_amd.learner import (GameHistory, Learner, ReplayBuffer, compute_priorities, support_ce_loss,
@@ -103,7 +104,7 @@ def check_against_g7(lrn, g7, rtol):
 
 def test_unrolled_loss_and_gradients_match_reference():
     g7 = load("g7_losses")
-    check_against_g7(g7_learner(g7, "cpu", "torch"), g7, rtol=2e-5)
+    check_against_g7(g7_learner(g7, "cpu", support_ce), g7, rtol=2e-5)
 
 
 def test_unroll_action_order():
@@ -113,7 +114,7 @@ def test_unroll_action_order():
 
 def test_update_weights_steps_and_reports_priorities():
     g7 = load("g7_losses")
-    lrn = g7_learner(g7, "cpu", "torch")
+    lrn = g7_learner(g7, "cpu", support_ce)
     before = {k: v.clone() for k, v in lrn.network.state_dict().items()}
     m = lrn.update_weights(g7_batch(g7), g7["weights"])
     np.testing.assert_allclose(m["priorities"], g7["per_sample"], rtol=2e-5)
@@ -174,7 +175,7 @@ def test_reference_checkpoint_resumes_training(tmp_path):
     assert set(ck) == set(checkpoint.KEYS) and ck["training_step"] == 2
     cfg = checkpoint.config_from(ck)
     assert cfg.downsample_steps == [(8, 2), (16, 3)] and cfg.support_size == 10 and cfg.lr_init == 0.05
-    lrn = Learner.from_checkpoint(path, device="cpu", loss_impl="torch")
+    lrn = Learner.from_checkpoint(path, device="cpu", loss_impl=support_ce)
     assert lrn.training_step == 2 and lrn.scheduler.last_epoch == 2
     m = lrn.update_weights(g7_batch(g7), g7["weights"])
     np.testing.assert_allclose(m["priorities"], g9["per_sample_step3"], rtol=2e-5)
@@ -187,7 +188,7 @@ def test_reference_checkpoint_resumes_training(tmp_path):
     assert set(ck2) == set(ck) and ck2["training_step"] == 3
     assert set(ck2["model_state_dict"]) == set(ck["model_state_dict"])
     assert set(ck2["config"]) >= set(ck["config"]) - {"eval_interval", "eval_episodes", "num_workers"}
-    again = Learner.from_checkpoint(out, device="cpu", loss_impl="torch")
+    again = Learner.from_checkpoint(out, device="cpu", loss_impl=support_ce)
     for (k, a), (_, b) in zip(again.network.state_dict().items(), lrn.network.state_dict().items()):
         assert torch.equal(a, b), k
     mom = lambda l: [st["momentum_buffer"] for st in l.optimizer.state_dict()["state"].values()]

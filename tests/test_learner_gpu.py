@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.loss import support_ce
 from tests.helpers import load
 from tests.test_learner_cpu import build_games, check_against_g7, g7_batch, g7_learner
 
@@ -81,7 +82,8 @@ def _edge_targets(S):
 
 @pytest.mark.parametrize("S", [10, 300])
 def test_support_ce_matches_reference_ops(S):
-    from muzero_amd.learner import _support_ce_torch, support_ce_loss
+    from muzero_amd.learner import support_ce_loss
+    from oracle.loss import support_ce as _support_ce_torch
     rng = np.random.default_rng(S)
     t = np.concatenate([_edge_targets(S), rng.normal(0, 30, 1000).astype(np.float32)])
     x = rng.normal(0, 2, (t.size, 2 * S + 1)).astype(np.float32)
@@ -133,7 +135,7 @@ def test_device_training_step_matches_reference():
 
 def test_hip_and_torch_loss_agree_on_device():
     g7 = load("g7_losses")
-    a, b = g7_learner(g7, "cuda", "hip"), g7_learner(g7, "cuda", "torch")
+    a, b = g7_learner(g7, "cuda", "hip"), g7_learner(g7, "cuda", support_ce)
     ra = a.update_weights(g7_batch(g7), g7["weights"])
     rb = b.update_weights(g7_batch(g7), g7["weights"])
     np.testing.assert_allclose(ra["priorities"], rb["priorities"], rtol=1e-5)

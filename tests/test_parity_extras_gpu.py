@@ -1,0 +1,93 @@
+"""Direct device checks of two pieces the search tests only reach indirectly, and the guard on what
+the throughput precision does to the search result."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_prepare_observation_on_the_reference_own_pair():
+    """g7 holds the uint8 observations the reference's compute_losses consumed, g9 what the
+    reference's prepare_observation (train.py:529-540) made of them."""
+    from muzero_amd.prep import prepare_observation
+    g7, g9 = load("g7_losses"), load("g9_outputs")
+    got = prepare_observation(torch.from_numpy(g7["obs"])).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == g9["obs"].shape
+    assert np.array_equal(got, g9["obs"])
+
+
+def test_ucb_score_device_arithmetic_bit_exact():
+    """The 4000 (parent visits, child visits, value sum, bounds, prior) tuples of g5 through the
+    device's own scoring function: float32 scores for float32 priors, float64 for float64 priors."""
+    from muzero_amd import _lib
+    from muzero_amd.tree import score_tables
+    g = load("g5_ucb")
+    n = g["pn"].shape[0]
+    dev = "cuda"
+    pbc, sq = score_tables(float(g["c_base"]), float(g["c_init"]), int(g["pn"].max()) + 2)
+    lo = np.where(g["unset"], np.inf, g["lo"])
+    hi = np.where(g["unset"], -np.inf, g["hi"])
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    pn, cn, cw = t(g["pn"], torch.int32), t(g["cn"], torch.int32), t(g["cw"], torch.float64)
+    lo_d, hi_d = t(lo, torch.float64), t(hi, torch.float64)
+    pbc_d, sq_d = t(pbc, torch.float64), t(sq, torch.float64)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    p32, p64 = t(g["p32"], torch.float32), t(g["p64"], torch.float64)
+    _lib.call("mz_ucb_score", _lib.ptr(pn), _lib.ptr(cn), _lib.ptr(cw), _lib.ptr(lo_d), _lib.ptr(hi_d), _lib.ptr(p32),
+              None, _lib.ptr(pbc_d), _lib.ptr(sq_d), len(pbc), n, _lib.ptr(out), _lib.current_stream())
+    got32 = out.cpu().numpy()
+    assert np.array_equal(got32.astype(np.float32).astype(np.float64), got32)      # float32 values, widened
+    assert np.array_equal(got32.astype(np.float32), g["s32"])
+    _lib.call("mz_ucb_score", _lib.ptr(pn), _lib.ptr(cn), _lib.ptr(cw), _lib.ptr(lo_d), _lib.ptr(hi_d), None,
+              _lib.ptr(p64), _lib.ptr(pbc_d), _lib.ptr(sq_d), len(pbc), n, _lib.ptr(out), _lib.current_stream())
+    assert np.array_equal(out.cpu().numpy(), g["s64"])
+
+
+def search_both(A, B, sims, precisions):
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.prep import FrameRing
+    from muzero_amd.search import BatchedMCTS
+    cfg = MuZeroConfig()
+    cfg.action_space_size, cfg.num_simulations = A, sims
+    sd = init_state_dict(cfg, seed=0, randomize_bn=True)
+    rng = np.random.default_rng(0)
+    ring = FrameRing(B)
+    ring.reset(torch.from_numpy(rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8)))
+    for _ in range(31):
+        ring.push(torch.from_numpy(rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8)))
+    noise = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=B)).cuda()
+    res = {}
+    for precision in precisions:
+        net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
+        m = BatchedMCTS(cfg, net, B, sims)
+        r = m.run(ring.observation(net.act_dtype), noise)
+        m.check_status()
+        res[precision] = (r.visit_counts.cpu().numpy().copy(), r.root_values.cpu().numpy().copy())
+        del m, net
+    return res
+
+
+# measured on MI355X with these seeds (128 games x 50 sims, random-init weights, randomised BatchNorm):
+#   A=18: identical visit counts 92 %, same most-visited action 100 %, mean total variation 0.2 %
+#   A=6 : 73 %, 95 %, 1.7 %;   root values differ by 2.5-3 % of their mean magnitude
+# the bounds are ~1.5x those figures
+@pytest.mark.parametrize("A,min_identical,min_same_top,max_tv,max_value", [(18, 0.86, 0.97, 0.0035, 0.045),
+                                                                            (6, 0.60, 0.90, 0.027, 0.045)])
+def test_bf16_search_stays_close_to_fp32_search(A, min_identical, min_same_top, max_tv, max_value):
+    """Same weights, observations and noise searched in the validation precision (fp32) and in the
+    throughput precision (bf16): how far the visit distributions and root values move."""
+    B, sims = 128, 50
+    res = search_both(A, B, sims, ("fp32", "bf16"))
+    (v32, q32), (v16, q16) = res["fp32"], res["bf16"]
+    tv = 0.5 * np.abs(v32 - v16).sum(1) / sims
+    stats = dict(identical=float((v32 == v16).all(1).mean()), same_top=float((v32.argmax(1) == v16.argmax(1)).mean()),
+                 tv=float(tv.mean()), value=float(np.abs(q32 - q16).mean() / np.abs(q32).mean()))
+    print("bf16 vs fp32 search", A, stats)
+    assert stats["identical"] >= min_identical, stats
+    assert stats["same_top"] >= min_same_top, stats
+    assert stats["tv"] <= max_tv, stats
+    assert stats["value"] <= max_value, stats
