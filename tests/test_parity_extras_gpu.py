@@ -75,7 +75,7 @@ def search_both(A, B, sims, precisions):
 #   A=18: identical visit counts 92 %, same most-visited action 100 %, mean total variation 0.2 %
 #   A=6 : 73 %, 95 %, 1.7 %;   root values differ by 2.5-3 % of their mean magnitude
 # the bounds are ~1.5x those figures
-@pytest.mark.parametrize("A,min_identical,min_same_top,max_tv,max_value", [(18, 0.86, 0.97, 0.0035, 0.045),
+@pytest.mark.parametrize("A,min_identical,min_same_top,max_tv,max_value", [(18, 0.88, 0.97, 0.013, 0.04),
                                                                             (6, 0.60, 0.90, 0.027, 0.045)])
 def test_bf16_search_stays_close_to_fp32_search(A, min_identical, min_same_top, max_tv, max_value):
     """Same weights, observations and noise searched in the validation precision (fp32) and in the
