@@ -323,6 +323,18 @@ int mz_replay_sample(const double* prio, int64_t n, const double* u, int32_t bat
                      const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game, int32_t* pos,
                      double* weights, void* workspace, int64_t workspace_bytes, mz_stream_t stream);
 
+/* mz_replay_sample without a workspace argument and without any allocation: the chunk sums and their scan go
+ * to a file-scope device array inside the library (128 KiB, held by every GPU the library has run on until the
+ * process ends).  No counterpart in the reference; it is for callers that cannot allocate device memory or
+ * carry a workspace around - code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  n must not exceed mz_replay_static_max_positions() (16 Mi positions; MZ_E_ARG otherwise).  All
+ * calls on one GPU share the array: the results of a call are complete once its stream work has finished, but
+ * two calls running at the same time on different streams of one GPU race on it. */
+int64_t mz_replay_static_max_positions(void);
+int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int32_t batch, double beta,
+                            const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game,
+                            int32_t* pos, double* weights, mz_stream_t stream);
+
 /* ReplayBuffer.update_priorities (model.py:612-614): prio[flat[i]] = (values[i] + 1e-6) ** alpha for i in list
  * order (of several entries naming one slot the last wins).  flat holds FLAT position indices as
  * mz_replay_sample returns them (the reference passes in-game offsets here, model.py:595 / :607, and so writes

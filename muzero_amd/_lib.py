@@ -63,6 +63,9 @@ _SIGNATURES = {
     "mz_replay_workspace_bytes": (C.c_int64, [C.c_int64]),
     "mz_replay_sample": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_double, _P, C.c_int32, _P, _P, _P, _P, _P,
                                    C.c_int64, _P]),
+    "mz_replay_static_max_positions": (C.c_int64, []),
+    "mz_replay_sample_static": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_double, _P, C.c_int32, _P, _P, _P, _P,
+                                          _P]),
     "mz_replay_update": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int32, C.c_double, _P]),
 }
 

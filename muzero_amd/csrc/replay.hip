@@ -218,6 +218,27 @@ int check_sample_args(const double* prio, int64_t n, const double* u, int32_t ba
   return MZ_OK;
 }
 
+// --- the allocation-free variant's scratch: one array per GPU, held until the process ends ---
+constexpr long kStaticMaxPositions = 16L << 20;  // 16 Mi positions -> 8192 chunks -> 128 KiB + 16 B
+constexpr long kStaticDoubles = 1 + (kStaticMaxPositions / kChunk + 1) + kStaticMaxPositions / kChunk;
+static __device__ __align__(256) double scratch[kStaticDoubles];
+
+double* static_scratch_ptr(int* rc) {
+  static double* ptr[mz::kMaxDevices] = {nullptr};
+  const int dev = mz::current_device();
+  *rc = MZ_OK;
+  if (!ptr[dev]) {  // once per device, with that device current: each GPU has its own copy of the array
+    double* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) {
+      *rc = mz::fail(MZ_E_LAUNCH, "mz_replay_sample_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    ptr[dev] = p;
+  }
+  return ptr[dev];
+}
+
 }  // namespace
 
 extern "C" {
@@ -234,6 +255,22 @@ int mz_replay_sample(const double* prio, int64_t n, const double* u, int32_t bat
   MZ_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "mz_replay_sample: workspace must be 8-byte aligned");
   return sample_impl(prio, n, u, batch, beta, reinterpret_cast<const long*>(game_start), n_games, flat, game, pos,
                      weights, static_cast<double*>(workspace), mz::as_stream(stream));
+}
+
+int64_t mz_replay_static_max_positions(void) { return kStaticMaxPositions; }
+
+int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int32_t batch, double beta,
+                            const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game,
+                            int32_t* pos, double* weights, mz_stream_t stream) {
+  if (int rc = check_sample_args(prio, n, u, batch, game_start, n_games, flat, game, pos, weights)) return rc;
+  MZ_REQUIRE(n <= kStaticMaxPositions,
+             "mz_replay_sample_static: %lld positions, at most %lld fit the built-in scratch (use mz_replay_sample "
+             "with a workspace)", (long long)n, (long long)kStaticMaxPositions);
+  int rc = MZ_OK;
+  double* ws = static_scratch_ptr(&rc);
+  if (!ws) return rc;
+  return sample_impl(prio, n, u, batch, beta, reinterpret_cast<const long*>(game_start), n_games, flat, game, pos,
+                     weights, ws, mz::as_stream(stream));
 }
 
 int mz_replay_update(double* prio, int64_t n, const int32_t* flat, const double* values, int32_t m, double alpha,
