@@ -151,7 +151,7 @@ def main():
 
     replay = None
     if args.graph:
-        worker.ring.observation(net.act_dtype, out=worker.obs)
+        worker.ring.observation(net.obs_dtype, out=worker.obs)
         replay = worker.mcts.capture(worker.obs, worker.noise)
 
     def one_step():
@@ -160,7 +160,7 @@ def main():
         if replay is None:
             return worker.step(frames)[0]
         worker.ring.push(frames)
-        worker.ring.observation(net.act_dtype, out=worker.obs)
+        worker.ring.observation(net.obs_dtype, out=worker.obs)
         res = replay()
         return select_actions(res.visit_counts, 1.0, worker.u)
 

@@ -204,6 +204,39 @@ int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stri
                        int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
                        float* mean_out, int32_t B, mz_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ * float32-accurate networks on the bf16 matrix cores ("bf16x3"): a float32 tensor travels as
+ * bf16 pairs hi = bf16(x), lo = bf16(x - hi), laid out [image][2 = hi, lo][pixels][channels], and
+ * every product is w_hi*x_hi + w_lo*x_hi + w_hi*x_lo accumulated in float32 (error ~2^-17
+ * relative per product).  This is the precision in which initial_inference / recurrent_inference
+ * (model.py:332-348) meet the reference's float32 outputs to 1e-3 at matrix-core speed.
+ * Weights: two fragment arrays in mz_conv3x3_bf16's packing, from bf16(w) and bf16(w - bf16(w)).
+ * ------------------------------------------------------------------ */
+
+/* float32 [n_images][per_image] -> split pairs [n_images][2][per_image] (bf16) and back (hi + lo, exact). */
+int mz_split_f32(const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream);
+int mz_join_f32(const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream);
+
+/* mz_conv3x3_bf16 on split tensors for the four layer shapes outside the 12x12 trunk (model.py:165-167, :182):
+ * out = act(conv(in) + bias [+ residual]), bias / residual / ReLU applied in float32 before the split. */
+int mz_conv3x3_bf16x3(const void* in, const void* wpk_hi, const void* wpk_lo, const float* bias, const void* residual,
+                      void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
+                      int32_t relu, mz_stream_t stream);
+
+/* mz_conv_chain_bf16 on split tensors: the dynamics network or the 12x12 tail of the representation network
+ * (model.py:236-241, :201-202) as one kernel with a game's (hi, lo) pair resident in LDS.  in_slot, action_vec +
+ * actions (added in float32) and mean_out (of the float32 outputs) as for mz_conv_chain_bf16. */
+typedef struct mz_chain_layer_x3 {
+  const void* wpk_hi;
+  const void* wpk_lo;
+  const float* bias;
+  int32_t relu;
+  int32_t add_residual;
+} mz_chain_layer_x3;
+int mz_conv_chain_bf16x3(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer_x3* layers,
+                         int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                         float* mean_out, int32_t B, mz_stream_t stream);
+
 /* x.mean(dim=(2,3)) (model.py:243, :275): float NHWC [B][HW][C] -> [B][C]. */
 int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
 

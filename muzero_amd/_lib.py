@@ -29,6 +29,11 @@ _P = C.c_void_p
 class ChainLayer(C.Structure):
     _fields_ = [("wpk", C.c_void_p), ("bias", C.c_void_p), ("relu", C.c_int32), ("add_residual", C.c_int32)]
 
+class ChainLayerX3(C.Structure):
+    _fields_ = [("wpk_hi", C.c_void_p), ("wpk_lo", C.c_void_p), ("bias", C.c_void_p), ("relu", C.c_int32),
+                ("add_residual", C.c_int32)]
+
+
 _SIGNATURES = {
     "mz_version": (C.c_int, []),
     "mz_last_error": (C.c_char_p, []),
@@ -45,6 +50,10 @@ _SIGNATURES = {
     "mz_conv3x3_bf16_info": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mz_conv3x3_bf16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_conv_chain_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "mz_split_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "mz_join_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "mz_conv3x3_bf16x3": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [_P]),
+    "mz_conv_chain_bf16x3": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "mz_spatial_mean_f32": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_heads": (C.c_int, [_P] + [C.c_int32] * 5 + [_P] * 10),
     "mz_support_to_scalar": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

@@ -1,0 +1,67 @@
+// Shared by the convolution translation units: vector types, the tiling description of the
+// patch kernels and the reference architecture's layer shapes, the geometry of the 12x12 trunk.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, int MINW_, int PF_ = 2, int NW_ = 4>
+struct Cfg {
+  static constexpr int NW = NW_;          // wavefronts per workgroup; they split the output channels
+  static constexpr int THREADS = 64 * NW_;
+  static constexpr int PF = PF_;  // weight prefetch distance in k-steps (1 or 2)
+  static constexpr int CIN = CIN_, CINC = CINC_, COUT = COUT_, S = S_, TH = TH_, TW = TW_, HIN = HIN_, WIN = WIN_;
+  static constexpr int MINW = MINW_;
+  static constexpr int HO = (HIN - 1) / S + 1, WO = (WIN - 1) / S + 1;
+  static constexpr int PY = HO / TH, PX = WO / TW;
+  static constexpr int M = TH * TW, MT = (M + 15) / 16;
+  static constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;  // input window incl. the halo
+  static constexpr int ROWB = CINC * 2 + 16;
+  static constexpr int KC = CINC / 32, NCC = CIN / CINC;
+  static constexpr int NTILES = COUT / 16, WN = NTILES / NW;
+  static constexpr int LDS_BYTES = IH * IW * ROWB;
+  static constexpr int KSTEPS = NCC * 9 * KC;
+  static_assert(HO % TH == 0 && WO % TW == 0, "patches must tile the output");
+  static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % (16 * NW) == 0, "channel tiling");
+};
+
+// The reference architecture's convolution shapes (model.py:178-215 with the default config)
+// other than the 12x12 trunk.  Eight wavefronts per workgroup measured 10-20 % faster than four
+// on the three strided layers (more loads in flight per CU); the 24x24 layer did not care.
+//                     CIN CINC COUT S TH TW  HIN WIN waves/SIMD PF NW
+#ifndef MZ_STEM_TH
+#define MZ_STEM_TH 8
+#define MZ_STEM_TW 8
+#define MZ_STEM_NW 8
+#define MZ_STEM_MINW 2
+#endif
+using ConvStem = Cfg<96, 96, 256, 2, MZ_STEM_TH, MZ_STEM_TW, 96, 96, MZ_STEM_MINW, 2, MZ_STEM_NW>;  // representation.conv1
+using ConvStemRot = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2, 2, 8>;   // the same layer on the rotating, tiled observation
+using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, 2, 2, 8>;   // downsample.0.conv
+using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, 3, 2, 4>;   // downsample.0.blocks
+using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, 2, 2, 8>;  // downsample.1.conv
+
+
+// ---- the 12x12x256 trunk (conv_trunk.hip, conv_x3.hip): planar LDS image [16-byte channel chunk][pixel]
+constexpr int kPix = 144, kSide = 12, kCh = 256;
+constexpr int kPixPad = 160;                 // pixels per plane incl. the zero pixels
+constexpr int kPlaneB = kPixPad * 16;        // bytes per channel-chunk plane
+constexpr int kPlanes = kCh / 8;             // 32 planes of 8 channels
+constexpr int kLdsBytes = kPlanes * kPlaneB; // 81 920
+constexpr int kMT = kPix / 16;               // 9 pixel tiles
+constexpr int kKC = kCh / 32;                // 8 k-steps per tap
+constexpr int kMaxChain = 20;
+
+// lanes (bit l: lane l, pixel mt*16 + l%16 of a row-major 12-wide image) whose pixel sits in column x_edge
+__host__ __device__ constexpr unsigned long long edge_lanes(int mt, int x_edge) {
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; ++l)
+    if ((mt * 16 + (l & 15)) % kSide == x_edge) m |= 1ull << l;
+  return m;
+}
+
+}  // namespace

@@ -16,20 +16,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kPix = 144, kSide = 12, kCh = 256;
-constexpr int kPixPad = 160;                 // pixels per plane incl. the zero pixels
-constexpr int kPlaneB = kPixPad * 16;        // bytes per channel-chunk plane
-constexpr int kPlanes = kCh / 8;             // 32 planes of 8 channels
-constexpr int kLdsBytes = kPlanes * kPlaneB; // 81 920
-constexpr int kMT = kPix / 16;               // 9 pixel tiles
-constexpr int kKC = kCh / 32;                // 8 k-steps per tap
 
 struct TrunkArgs {
   const __bf16* in;
@@ -241,16 +230,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
 // (2..3 x 72 KB) per layer, has no per-layer launch, and needs one workgroup
 // barrier per layer.  Workgroups are persistent: each walks images b, b+grid, ...
 // ---------------------------------------------------------------------------
-constexpr int kMaxChain = 20;
-
-// lanes (bit l: lane l, pixel mt*16 + l%16 of a row-major 12-wide image) whose pixel sits in column x_edge
-__host__ __device__ constexpr unsigned long long edge_lanes(int mt, int x_edge) {
-  unsigned long long m = 0;
-  for (int l = 0; l < 64; ++l)
-    if ((mt * 16 + (l & 15)) % kSide == x_edge) m |= 1ull << l;
-  return m;
-}
-
 #ifndef MZ_CHAIN_PF
 #define MZ_CHAIN_PF 2
 #endif

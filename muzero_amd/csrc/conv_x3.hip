@@ -1,0 +1,563 @@
+// float32-accurate 3x3 convolutions on the bf16 matrix cores ("bf16x3"): every float32 value
+// x travels as a pair of bf16 values (hi, lo) with hi = bf16(x), lo = bf16(x - hi), which
+// carries 16-17 significant bits, and a product w * x is formed as
+//     w_hi * x_hi + w_lo * x_hi + w_hi * x_lo
+// by three v_mfma_f32_16x16x32_bf16 into one float32 accumulator (the dropped lo * lo term and
+// the rounding of the lo parts are ~2^-17 relative).  This is the precision in which the
+// networks meet the reference's float32 outputs to 1e-3 (model.py:332-348 on the torch CPU
+// path); the matrix pipe runs three times the bf16 kernels' work.
+//
+// A split tensor is stored component-major per image: [image][2 = hi, lo][pixels][channels].
+// Weights are two fragment arrays in the packing of mz_conv3x3_bf16 (hi and lo parts).
+// The kernels are the bf16 ones' designs (conv_bf16.hip, conv_trunk.hip) with the second
+// component in the place of the second image / a second LDS window.
+#include "common.h"
+#include "conv_common.h"
+
+namespace {
+
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4& hi, bf16x4& lo) {
+  hi = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+  lo = bf16x4{(__bf16)(v0 - (float)hi[0]), (__bf16)(v1 - (float)hi[1]), (__bf16)(v2 - (float)hi[2]),
+              (__bf16)(v3 - (float)hi[3])};
+}
+
+// ---------------------------------------------------------------------------
+// Patch kernel for the four non-trunk layer shapes (cf. conv3x3_bf16_kernel)
+// ---------------------------------------------------------------------------
+struct X3Args {
+  const __bf16* in;
+  const __bf16* wpk_hi;
+  const __bf16* wpk_lo;
+  const float* bias;
+  const __bf16* residual;
+  __bf16* out;
+  int relu;
+};
+
+template <class C>
+__device__ __forceinline__ void stage_window(char* lds, const __bf16* src, int cc, int iy0, int ix0, int tid) {
+  constexpr int UPP = C::CINC / 8;
+  constexpr int UNITS = C::IH * C::IW * UPP;
+  constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int u = tid + i * C::THREADS;
+    if (u >= UNITS) break;
+    const int pix = u / UPP, cu = u % UPP;
+    const int py = pix / C::IW, px = pix % C::IW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN)
+      v = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
+    *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = v;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
+  constexpr int WIN_B = C::LDS_BYTES;  // one component's window; the lo window follows the hi window
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / (C::PY * C::PX), patch = blockIdx.x % (C::PY * C::PX);
+  const int oy0 = (patch / C::PX) * C::TH, ox0 = (patch % C::PX) * C::TW;
+  constexpr long IMG_IN = (long)C::HIN * C::WIN * C::CIN, IMG_OUT = (long)C::HO * C::WO * C::COUT;
+  const __bf16* src = a.in + (long)b * 2 * IMG_IN;
+  const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  f32x4 acc[MT][WN];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int WSTEP = C::NTILES * 1024;
+  const __amdgpu_buffer_rsrc_t wrh = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk_hi), 0,
+                                                                       (C::KSTEPS + 2) * WSTEP, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrl = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk_lo), 0,
+                                                                       (C::KSTEPS + 2) * WSTEP, 0x00020000);
+  const int wlane = wave * (WN * 1024) + lane * 16;
+  auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
+  };
+  bf16x8 wh[WN], wl[WN];
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    wh[nt] = wfrag(wrh, 0, nt);
+    wl[nt] = wfrag(wrl, 0, nt);
+  }
+  int wp = WSTEP;
+
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int m = mt * 16 + r16;
+    if (m >= C::M) m = C::M - 1;
+    const int py = m / C::TW, px = m % C::TW;
+    abase[mt] = lds_base + (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16;
+  }
+  constexpr int NS = 9 * KC;
+  auto step_offset = [](int st) {
+    const int tap = st / KC, kc = st % KC;
+    return ((tap / 3) * C::IW + tap % 3) * C::ROWB + kc * 64;
+  };
+
+  for (int cc = 0; cc < C::NCC; ++cc) {
+    if (cc > 0) __syncthreads();
+    stage_window<C>(lds, src, cc, iy0, ix0, tid);
+    stage_window<C>(lds + WIN_B, src + IMG_IN, cc, iy0, ix0, tid);
+    __syncthreads();
+    bf16x8 af[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[mt] = *(lds_frag_ptr)(abase[mt]);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      bf16x8 w2h[WN], w2l[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        w2h[nt] = wfrag(wrh, wp, nt);
+        w2l[nt] = wfrag(wrl, wp, nt);
+      }
+      wp += WSTEP;
+      // w_hi * x_hi, then w_lo * x_hi (after which the operand register takes x_lo), then w_hi * x_lo
+      // (after which it takes the next step's x_hi)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        af[mt] = *(lds_frag_ptr)(abase[mt] + (WIN_B + step_offset(st)));
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        if (st + 1 < NS) af[mt] = *(lds_frag_ptr)(abase[mt] + step_offset(st + 1));
+      }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2 * WN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * WN, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        wh[nt] = w2h[nt];
+        wl[nt] = w2l[nt];
+      }
+    }
+  }
+
+  // epilogue: bias, residual (hi + lo), ReLU in float32, split, parked in LDS as two tiles, stored as rows
+  constexpr int OROW = C::COUT * 2 + 16;
+  constexpr int TILE_B = C::M * OROW;
+  static_assert(2 * TILE_B <= 2 * C::LDS_BYTES, "output tiles must fit in the input windows' LDS");
+  __syncthreads();
+  const __bf16* res = a.residual ? a.residual + (long)b * 2 * IMG_OUT : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < WN; ++nt) {
+    const int cbase = (wave * WN + nt) * 16 + kq * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m < C::M) {
+        float v0 = acc[mt][nt][0] + bv.x, v1 = acc[mt][nt][1] + bv.y;
+        float v2 = acc[mt][nt][2] + bv.z, v3 = acc[mt][nt][3] + bv.w;
+        if (res) {
+          const int py = m / C::TW, px = m % C::TW;
+          const long o = (((long)oy0 + py) * C::WO + ox0 + px) * C::COUT + cbase;
+          const bf16x4 rh = *reinterpret_cast<const bf16x4*>(res + o);
+          const bf16x4 rl = *reinterpret_cast<const bf16x4*>(res + IMG_OUT + o);
+          v0 += (float)rh[0] + (float)rl[0]; v1 += (float)rh[1] + (float)rl[1];
+          v2 += (float)rh[2] + (float)rl[2]; v3 += (float)rh[3] + (float)rl[3];
+        }
+        if (a.relu) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        bf16x4 hi, lo;
+        split4(v0, v1, v2, v3, hi, lo);
+        *reinterpret_cast<bf16x4*>(lds + m * OROW + cbase * 2) = hi;
+        *reinterpret_cast<bf16x4*>(lds + TILE_B + m * OROW + cbase * 2) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int UPR = C::COUT / 8;
+  __bf16* dst = a.out + (long)b * 2 * IMG_OUT;
+  for (int u = tid; u < 2 * C::M * UPR; u += C::THREADS) {
+    const int comp = u / (C::M * UPR), r = u % (C::M * UPR);
+    const int m = r / UPR, c16 = r % UPR;
+    const int py = m / C::TW, px = m % C::TW;
+    const long o = (((long)oy0 + py) * C::WO + ox0 + px) * C::COUT + c16 * 8;
+    *reinterpret_cast<bf16x8*>(dst + comp * IMG_OUT + o) =
+        *reinterpret_cast<const bf16x8*>(lds + comp * TILE_B + m * OROW + c16 * 16);
+  }
+}
+
+template <class C>
+int launch_x3(const X3Args& a, int B, hipStream_t stream) {
+  static bool configured[mz::kMaxDevices] = {false};
+  auto kern = conv3x3_x3_kernel<C>;
+  constexpr int lds = 2 * C::LDS_BYTES;
+  static_assert(lds <= 160 * 1024, "two input windows must fit in a CU's LDS");
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv3x3_x3")) return rc;
+  hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), lds, stream, a);
+  return mz::check_launch("mz_conv3x3_bf16x3");
+}
+
+template <class C>
+bool matches(int H, int W, int Cin, int Cout, int stride) {
+  return H == C::HIN && W == C::WIN && Cin == C::CIN && Cout == C::COUT && stride == C::S;
+}
+
+// ---------------------------------------------------------------------------
+// Chain of 12x12 256->256 layers with one game's (hi, lo) pair resident in LDS
+// (cf. conv_chain_pair_kernel: the lo component sits where that kernel keeps its second image)
+// ---------------------------------------------------------------------------
+struct ChainX3Args {
+  const __bf16* in;
+  const int* in_slot;
+  int slot_stride;
+  __bf16* out;
+  const float* avec;
+  const int* actions;
+  float* mean_out;
+  int B;
+  int n_layers;
+  const __bf16* wpk_hi[kMaxChain];
+  const __bf16* wpk_lo[kMaxChain];
+  const float* bias[kMaxChain];
+  unsigned relu_mask;
+  unsigned res_mask;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NW = 8, WN = 2;
+  constexpr int WSTEP = 16 * 1024;
+  constexpr int PSTRIDE = 2 * kPlaneB;  // LDS bytes between consecutive planes of one component
+  constexpr int KOFF = PSTRIDE;
+  constexpr long IMG = (long)kPix * kCh;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int vb0 = lds_base + kq * (8 * PSTRIDE) + r16 * 16;
+  const int vz0 = lds_base + kq * (8 * PSTRIDE) + kPix * 16;
+  auto tap_addresses = [&](int tap, int (&addr)[kMT]) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int shift = (dy - 1) * kSide + (dx - 1);
+    const int t = vb0 + shift * 16;
+    const int z = vz0 + ((r16 + shift) & 15) * 16;
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      unsigned long long bad = dx == 0 ? edge_lanes(mt, 0) : dx == 2 ? edge_lanes(mt, kSide - 1) : 0ull;
+      if (mt == 0 && dy == 0) bad |= 0x0FFF0FFF0FFF0FFFull;
+      addr[mt] = __builtin_amdgcn_inverse_ballot_w64(bad) ? z : t + mt * 256;
+    }
+  };
+  auto plane_of = [](int q) { return (q & 3) * 8 + (q >> 2); };
+
+  {  // zero pixels of all 64 planes (never written afterwards)
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64)
+      *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
+  }
+
+  const int wlane = wave * (WN * 1024) + lane * 16;
+  auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
+  };
+  auto wdesc = [&](const __bf16* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+  };
+  const int pl = lane & 15, qq = lane >> 4;
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
+    const __bf16* src = a.in + img * 2 * IMG;
+    const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
+
+    __amdgpu_buffer_rsrc_t wrh = wdesc(a.wpk_hi[0]), wrl = wdesc(a.wpk_lo[0]);
+    bf16x8 wh[WN], wl[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+      wh[nt] = wfrag(wrh, 0, nt);
+      wl[nt] = wfrag(wrl, 0, nt);
+    }
+    int wp = WSTEP;
+
+#pragma unroll
+    for (int j = 0; j < 72 / NW; ++j) {  // both components -> LDS (planar); the action vector is added in float32
+      const int it = wave + NW * j;
+      const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+      bf16x8 vh = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
+      bf16x8 vl = *reinterpret_cast<const bf16x8*>(src + IMG + pix * kCh + q * 8);
+      if (av) {
+        const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+        const float add[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = ((float)vh[e] + (float)vl[e]) + add[e];
+          vh[e] = (__bf16)v;
+          vl[e] = (__bf16)(v - (float)vh[e]);
+        }
+      }
+      *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2) * kPlaneB + pix * 16) = vh;
+      *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + 1) * kPlaneB + pix * 16) = vl;
+    }
+    __syncthreads();
+
+    f32x4 acc[kMT][WN];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int l = 0; l < a.n_layers; ++l) {
+      const bool last = l == a.n_layers - 1;
+      const int ln = last ? l : l + 1;
+      const __amdgpu_buffer_rsrc_t wrh_next = wdesc(a.wpk_hi[ln]), wrl_next = wdesc(a.wpk_lo[ln]);
+
+      int aaddr[kMT];
+      tap_addresses(0, aaddr);
+      bf16x8 af[kMT];
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) af[mt] = *(lds_frag_ptr)(aaddr[mt]);
+
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int kc = 0; kc < kKC; ++kc) {
+          bf16x8 w2h[WN], w2l[WN];
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            w2h[nt] = wfrag(wrh, wp, nt);
+            w2l[nt] = wfrag(wrl, wp, nt);
+          }
+          wp += WSTEP;
+          // w_hi * x_hi
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+          // w_lo * x_hi; each operand register is then refilled with x_lo of this k-step
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kPlaneB + kc * KOFF));
+          }
+          __builtin_amdgcn_sched_group_barrier(0x020, 2 * WN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, kMT * WN, 0);
+#pragma unroll
+          for (int i = 0; i < kMT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (kc == kKC - 1) tap_addresses(tap < 8 ? tap + 1 : 8, aaddr);
+          // w_hi * x_lo; refill with x_hi of the next k-step
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
+          }
+#pragma unroll
+          for (int i = 0; i < kMT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nt = 0; nt < WN; ++nt) {
+            wh[nt] = w2h[nt];
+            wl[nt] = w2l[nt];
+          }
+        }
+      }
+
+      float4 bv[WN];
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt)
+        bv[nt] = *reinterpret_cast<const float4*>(a.bias[l] + (wave * WN + nt) * 16 + kq * 4);
+      __syncthreads();  // every wavefront has read the layer's input: it may be overwritten
+      const bool relu = (a.relu_mask >> l) & 1u;
+      const bool keep_input = !last && ((a.res_mask >> (l + 1)) & 1u);  // the next layer adds this layer's input
+      if (!last) {
+        wrh = wrh_next;
+        wrl = wrl_next;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+          wh[nt] = wfrag(wrh, 0, nt);
+          wl[nt] = wfrag(wrl, 0, nt);
+        }
+        wp = WSTEP;
+      }
+      const float floor_v = relu ? 0.f : -__builtin_inff();
+      const bool want_mean = last && a.mean_out;
+#pragma unroll
+      for (int nt = 0; nt < WN; ++nt) {
+        const int cbase = (wave * WN + nt) * 16 + kq * 4;
+        char* plane = lds + (plane_of(cbase >> 3) * 2) * kPlaneB + (cbase & 4) * 2;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < kMT; ++mt) {
+          char* slot = plane + (mt * 16 + r16) * 16;
+          const float v0 = fmaxf(acc[mt][nt][0] + bv[nt].x, floor_v), v1 = fmaxf(acc[mt][nt][1] + bv[nt].y, floor_v);
+          const float v2 = fmaxf(acc[mt][nt][2] + bv[nt].z, floor_v), v3 = fmaxf(acc[mt][nt][3] + bv[nt].w, floor_v);
+          // the next layer's starting value: this layer's input (hi + lo, exact in float32) where the
+          // next layer adds it, else zero
+          if (keep_input) {
+            const bf16x4 rh = *reinterpret_cast<const bf16x4*>(slot);
+            const bf16x4 rl = *reinterpret_cast<const bf16x4*>(slot + kPlaneB);
+            acc[mt][nt] = f32x4{(float)rh[0] + (float)rl[0], (float)rh[1] + (float)rl[1], (float)rh[2] + (float)rl[2],
+                                (float)rh[3] + (float)rl[3]};
+          } else {
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+          bf16x4 hi, lo;
+          split4(v0, v1, v2, v3, hi, lo);
+          *reinterpret_cast<bf16x4*>(slot) = hi;
+          *reinterpret_cast<bf16x4*>(slot + kPlaneB) = lo;
+        }
+        if (want_mean) {
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) {
+            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
+          }
+          if (r16 == 0) {
+            const float inv = 1.0f / (float)kPix;
+            *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
+                make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    __bf16* dst = a.out + (long)b * 2 * IMG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        *reinterpret_cast<bf16x8*>(dst + i * IMG + pix * kCh + q * 8) =
+            *reinterpret_cast<const bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + pix * 16);
+      }
+    __syncthreads();  // the next game overwrites these
+  }
+}
+
+// float32 [n] <-> split bf16 pairs laid out [n / per_image][2][per_image]
+__global__ void split_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long n, long per_image) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long img = i / per_image, r = i - img * per_image;
+  const float v = x[i];
+  const __bf16 hi = (__bf16)v;
+  out[img * 2 * per_image + r] = hi;
+  out[img * 2 * per_image + per_image + r] = (__bf16)(v - (float)hi);
+}
+__global__ void join_kernel(const __bf16* __restrict__ x, float* __restrict__ out, long n, long per_image) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long img = i / per_image, r = i - img * per_image;
+  out[i] = (float)x[img * 2 * per_image + r] + (float)x[img * 2 * per_image + per_image + r];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mz_conv3x3_bf16x3(const void* in, const void* wpk_hi, const void* wpk_lo, const float* bias, const void* residual,
+                      void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
+                      int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(in && wpk_hi && wpk_lo && bias && out && B > 0, "mz_conv3x3_bf16x3: null tensor or empty batch");
+  X3Args a{static_cast<const __bf16*>(in), static_cast<const __bf16*>(wpk_hi), static_cast<const __bf16*>(wpk_lo),
+           bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), relu};
+  hipStream_t s = mz::as_stream(stream);
+  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch_x3<ConvStem>(a, B, s);
+  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch_x3<ConvDown0>(a, B, s);
+  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch_x3<ConvMid>(a, B, s);
+  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch_x3<ConvDown1>(a, B, s);
+  return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16x3: no kernel for %dx%d, %d->%d channels, stride %d (the 12x12 "
+                  "256->256 layers go through mz_conv_chain_bf16x3)", H, W, Cin, Cout, stride);
+}
+
+int mz_conv_chain_bf16x3(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer_x3* layers,
+                         int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                         float* mean_out, int32_t B, mz_stream_t stream) {
+  MZ_REQUIRE(in && layers && out && B > 0, "mz_conv_chain_bf16x3: null tensor or empty batch");
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= kMaxChain, "mz_conv_chain_bf16x3: n_layers must be 1..20 (got %d)", n_layers);
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv_chain_bf16x3: action_vec and actions go together");
+  MZ_REQUIRE(!layers[0].add_residual, "mz_conv_chain_bf16x3: the first layer has no residual source");
+  ChainX3Args a{};
+  a.in = static_cast<const __bf16*>(in);
+  a.in_slot = in_slot;
+  a.slot_stride = slot_stride;
+  a.out = static_cast<__bf16*>(out);
+  a.avec = action_vec;
+  a.actions = actions;
+  a.mean_out = mean_out;
+  a.B = B;
+  a.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    MZ_REQUIRE(layers[l].wpk_hi && layers[l].wpk_lo && layers[l].bias, "mz_conv_chain_bf16x3: layer %d is null", l);
+    a.wpk_hi[l] = static_cast<const __bf16*>(layers[l].wpk_hi);
+    a.wpk_lo[l] = static_cast<const __bf16*>(layers[l].wpk_lo);
+    a.bias[l] = layers[l].bias;
+    if (layers[l].relu) a.relu_mask |= 1u << l;
+    if (layers[l].add_residual) a.res_mask |= 1u << l;
+  }
+  constexpr int lds = 2 * kLdsBytes;
+  static bool configured[mz::kMaxDevices] = {false};
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_chain_x3_kernel), lds, configured,
+                                      "conv_chain_x3"))
+    return rc;
+  const int n_cu = mz::compute_units();
+  hipLaunchKernelGGL(conv_chain_x3_kernel, dim3(B < n_cu ? B : n_cu), dim3(512), lds, mz::as_stream(stream), a);
+  return mz::check_launch("mz_conv_chain_bf16x3");
+}
+
+int mz_split_f32(const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "mz_split_f32: bad arguments");
+  const long n = n_images * per_image;
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream), x,
+                     static_cast<__bf16*>(out), n, (long)per_image);
+  return mz::check_launch("mz_split_f32");
+}
+
+int mz_join_f32(const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "mz_join_f32: bad arguments");
+  const long n = n_images * per_image;
+  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream),
+                     static_cast<const __bf16*>(x), out, n, (long)per_image);
+  return mz::check_launch("mz_join_f32");
+}
+
+}  // extern "C"

@@ -13,9 +13,11 @@ into the convolution weights when a ``state_dict`` is loaded.  Parameter names
 are the reference's, so a reference checkpoint's ``model_state_dict`` loads
 directly.
 
-Precisions: ``"fp32"`` - exact float32 kernels for any layer shape (validation);
-``"bf16"`` - bf16 MFMA kernels with float32 accumulation for the reference's
-default architecture (throughput).
+Precisions: ``"bf16"`` - bf16 MFMA kernels with float32 accumulation for the reference's
+default architecture (throughput); ``"bf16x3"`` - the same architecture with every float32 value
+carried as a (hi, lo) pair of bf16 values and three MFMAs per product: float32-accurate outputs
+(1e-3 against the reference's float32 path) at a third of the bf16 matrix rate; ``"fp32"`` - exact
+float32 kernels on the vector units for any layer shape (validation).
 """
 import ctypes as C
 import math
@@ -187,13 +189,15 @@ class _HeadWeights(C.Structure):
 class MuZeroNetwork:
     def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0,
                  input_hw=(96, 96)):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "bf16x3", "fp32"):
+            raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.config = config
         self.precision = precision
         self.device = torch.device(device)
-        self.act_dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+        self.split = precision == "bf16x3"     # activations are (hi, lo) bf16 pairs: [B, 2, H, W, C]
+        self.act_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.obs_dtype = torch.bfloat16 if precision == "bf16" else torch.float32   # what represent() takes
         self.A = config.action_space_size
         self.S = config.support_size
         self.W = config.num_channels
@@ -268,6 +272,9 @@ class MuZeroNetwork:
                 chunk, whole = mfma.kernel_info(h, w, layer.cin, layer.cout, layer.stride)
                 layer.whole_image = whole
                 layer.dev["w"] = mfma.pack_weights(layer.w, chunk).to(self.device)
+                if self.split:   # the part of the float32 weight its bf16 rounding leaves out
+                    rest = layer.w - layer.w.to(torch.bfloat16).float()
+                    layer.dev["w_lo"] = mfma.pack_weights(rest, chunk).to(self.device)
 
     # ---- scratch
     def _buf(self, tag, shape, dtype=None):
@@ -279,10 +286,27 @@ class MuZeroNetwork:
             self._buffers[key] = t
         return t
 
+    def act_shape(self, B, H, W, Cc):
+        """Shape of an activation tensor of B images in this precision's layout."""
+        return (B, 2, H, W, Cc) if self.split else (B, H, W, Cc)
+
+    def hidden_shape(self, h, w):
+        """Per-game shape of a hidden state in the device pool."""
+        return (2, h, w, self.W) if self.split else (h, w, self.W)
+
     # ---- kernels
     def _conv(self, layer: ConvLayer, x, out, H, W, relu=True, residual=None, in_slot=None, slot_stride=0,
               actions=None, mean_out=None, weights=None):
         B = out.shape[0]
+        if self.split:
+            if in_slot is not None or actions is not None or mean_out is not None or weights is not None:
+                raise NotImplementedError("bf16x3: gather / action / mean are fused only in the 12x12 chain kernel")
+            if (H, W, layer.cin, layer.cout, layer.stride) == (12, 12, 256, 256, 1):
+                raise NotImplementedError("bf16x3: 12x12 layers run through the chain kernel")
+            _lib.call("mz_conv3x3_bf16x3", _lib.ptr(x), _lib.ptr(layer.dev["w"]), _lib.ptr(layer.dev["w_lo"]),
+                      _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out), B, H, W, layer.cin, layer.cout,
+                      layer.stride, 1 if relu else 0, _lib.current_stream())
+            return
         weights = layer.dev["w"] if weights is None else weights
         if self.precision == "fp32":
             _lib.call("mz_conv3x3_f32", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(weights),
@@ -301,7 +325,7 @@ class MuZeroNetwork:
 
     def _chain_ok(self, convs, H, W) -> bool:
         """True when the fused LDS-resident chain kernel serves these layers."""
-        return (self.precision == "bf16" and H == 12 and W == 12 and 1 <= len(convs) <= 20
+        return (self.precision in ("bf16", "bf16x3") and H == 12 and W == 12 and 1 <= len(convs) <= 20
                 and all(c.cin == 256 and c.cout == 256 and c.stride == 1 for c in convs))
 
     def _chain(self, key, blocks, first, x, out, in_slot=None, slot_stride=0, actions=None, mean_out=None):
@@ -313,12 +337,18 @@ class MuZeroNetwork:
                 specs.append((first, 1, 0))
             for c1, c2 in blocks:
                 specs += [(c1, 1, 0), (c2, 1, 1)]
-            arr = (_lib.ChainLayer * len(specs))()
-            for i, (c, relu, res) in enumerate(specs):
-                arr[i] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), relu, res)
+            if self.split:
+                arr = (_lib.ChainLayerX3 * len(specs))()
+                for i, (c, relu, res) in enumerate(specs):
+                    arr[i] = _lib.ChainLayerX3(c.dev["w"].data_ptr(), c.dev["w_lo"].data_ptr(),
+                                               c.dev["bias"].data_ptr(), relu, res)
+            else:
+                arr = (_lib.ChainLayer * len(specs))()
+                for i, (c, relu, res) in enumerate(specs):
+                    arr[i] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), relu, res)
             cached = self._chains[key] = (arr, len(specs))
         arr, n = cached
-        _lib.call("mz_conv_chain_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
+        _lib.call("mz_conv_chain_bf16x3" if self.split else "mz_conv_chain_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
                   _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
                   _lib.ptr(mean_out), out.shape[0], _lib.current_stream())
 
@@ -386,7 +416,7 @@ class MuZeroNetwork:
             if obs_nhwc.dim() != 6 or obs_nhwc.shape[3] * 3 != self.cin:
                 raise ValueError("a rotating observation is [B, H, W/16, frames, 16, 3]")
             B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2] * 16
-            _lib.expect(obs_nhwc, "observation", self.act_dtype)
+            _lib.expect(obs_nhwc, "observation", self.obs_dtype)
             first = self.rep_plan[0][1]
             rot_kernel = (self.precision == "bf16" and (H, W, self.cin, first.cout) == (96, 96, 96, 256))
             if not rot_kernel:     # validation precision / other shapes: undo the tiling, keep the permuted weights
@@ -396,10 +426,14 @@ class MuZeroNetwork:
             B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2]
         hh, hw = self.hidden_hw(H, W)
         if not rot_kernel:
-            _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, H, W, self.cin))
-        _lib.expect(hidden_out, "hidden_out", self.act_dtype, (B, hh, hw, self.W))
+            _lib.expect(obs_nhwc, "observation", self.obs_dtype, (B, H, W, self.cin))
+        _lib.expect(hidden_out, "hidden_out", self.act_dtype, self.act_shape(B, hh, hw, self.W))
         _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
         x = obs_nhwc
+        if self.split:
+            if rotation is not None:
+                raise NotImplementedError("bf16x3 takes the observation in the reference's channel order")
+            x = self._split(obs_nhwc)
         plan = self.rep_plan
         # the trailing residual blocks at the hidden resolution run as one fused chain
         n_tail = 0
@@ -413,7 +447,7 @@ class MuZeroNetwork:
             final = i == last
             if kind == "conv":
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-                y = hidden_out if final else self._buf(("rep", i % 3), (B, HO, WO, item.cout))
+                y = hidden_out if final else self._buf(("rep", i % 3), self.act_shape(B, HO, WO, item.cout))
                 w = self._rotated_weights(item, rotation) if i == 0 and rotation is not None else None
                 if i == 0 and rot_kernel:
                     _lib.call("mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w), _lib.ptr(item.dev["bias"]), _lib.ptr(y),
@@ -423,8 +457,8 @@ class MuZeroNetwork:
                 x, H, W = y, HO, WO
             else:
                 c = item[0].cout
-                tmp = self._buf(("rep_tmp", H), (B, H, W, c))
-                y = hidden_out if final else self._buf(("rep", i % 3), (B, H, W, c))
+                tmp = self._buf(("rep_tmp", H), self.act_shape(B, H, W, c))
+                y = hidden_out if final else self._buf(("rep", i % 3), self.act_shape(B, H, W, c))
                 self._res_block(item, x, tmp, y, H, W, mean_out=mean_out if final else None)
                 x = y
         if fuse:
@@ -433,17 +467,18 @@ class MuZeroNetwork:
     def dynamics(self, pool: torch.Tensor, in_slot: Optional[torch.Tensor], slot_stride: int,
                  actions: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor) -> None:
         """hidden' = dynamics(pool[in_slot[b]*slot_stride + b], actions[b]) for every b."""
-        B, H, W, c = hidden_out.shape
-        _lib.expect(hidden_out, "hidden_out", self.act_dtype, (B, H, W, self.W))
+        B, (H, W, c) = hidden_out.shape[0], hidden_out.shape[-3:]
+        shape = self.act_shape(B, H, W, self.W)
+        _lib.expect(hidden_out, "hidden_out", self.act_dtype, shape)
         _lib.expect(actions, "actions", torch.int32, (B,))
         _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
         if in_slot is None:
-            _lib.expect(pool, "hidden_state", self.act_dtype, (B, H, W, self.W))
+            _lib.expect(pool, "hidden_state", self.act_dtype, shape)
         else:
             _lib.expect(in_slot, "in_slot", torch.int32, (B,))
             _lib.expect(pool, "pool", self.act_dtype)
-            if pool.dim() != 5 or tuple(pool.shape[1:]) != (B, H, W, self.W) or slot_stride != B:
-                raise ValueError(f"pool must be [slots, {B}, {H}, {W}, {self.W}] with slot_stride {B}")
+            if pool.dim() != len(shape) + 1 or tuple(pool.shape[1:]) != shape or slot_stride != B:
+                raise ValueError(f"pool must be [slots, {', '.join(map(str, shape))}] with slot_stride {B}")
         if self._chain_ok([self.dyn_first] + [l for blk in self.dyn_blocks for l in blk], H, W):
             timing = self.dynamics_events  # optional list: (start, end) event pairs around each launch
             if timing is not None:
@@ -455,6 +490,8 @@ class MuZeroNetwork:
                 e1.record()
                 timing.append((e0, e1))
             return
+        if self.split:
+            raise NotImplementedError("bf16x3 serves the reference architecture's 12x12x256 dynamics network only")
         a = self._buf("dyn_a", (B, H, W, c))
         t = self._buf("dyn_t", (B, H, W, c))
         cur, spare = a, self._buf("dyn_b", (B, H, W, c))
@@ -490,14 +527,36 @@ class MuZeroNetwork:
         return priors, value, reward
 
     # ---- the reference's call surface (NCHW float32 in and out)
-    def _to_nhwc(self, x_nchw: torch.Tensor) -> torch.Tensor:
+    def _split(self, x: torch.Tensor) -> torch.Tensor:
+        """float32 [B, ...] -> (hi, lo) bf16 pairs [B, 2, ...]."""
+        x = x.contiguous()
+        B, per = x.shape[0], x[0].numel()
+        y = torch.empty((B, 2) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=self.device)
+        _lib.call("mz_split_f32", _lib.ptr(x), _lib.ptr(y), B, per, _lib.current_stream())
+        return y
+
+    def _join(self, x: torch.Tensor) -> torch.Tensor:
+        """(hi, lo) bf16 pairs [B, 2, ...] -> float32 [B, ...]."""
+        B, per = x.shape[0], x[0, 0].numel()
+        y = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.float32, device=self.device)
+        _lib.call("mz_join_f32", _lib.ptr(x.contiguous()), _lib.ptr(y), B, per, _lib.current_stream())
+        return y
+
+    def _to_nhwc(self, x_nchw: torch.Tensor, as_obs: bool = False) -> torch.Tensor:
+        """NCHW float32 -> NHWC in the activation layout (as_obs: in the layout represent() takes)."""
         B, Cc, H, W = x_nchw.shape
         x = x_nchw.contiguous().float()
         y = torch.empty(B, H, W, Cc, dtype=torch.float32, device=self.device)
         _lib.call("mz_nchw_to_nhwc_f32", _lib.ptr(x), _lib.ptr(y), B, Cc, H * W, _lib.current_stream())
+        if as_obs:
+            return y if self.obs_dtype == torch.float32 else y.to(self.obs_dtype)
+        if self.split:
+            return self._split(y)
         return y if self.act_dtype == torch.float32 else y.to(self.act_dtype)
 
     def _to_nchw(self, x_nhwc: torch.Tensor) -> torch.Tensor:
+        if self.split:
+            x_nhwc = self._join(x_nhwc)
         B, H, W, Cc = x_nhwc.shape
         x = x_nhwc if x_nhwc.dtype == torch.float32 else x_nhwc.float()
         y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=self.device)
@@ -506,10 +565,10 @@ class MuZeroNetwork:
 
     def initial_inference(self, observation: torch.Tensor) -> NetworkOutput:
         """model.py:332-338.  observation: float32 [B, C, H, W] on the device."""
-        obs = self._to_nhwc(observation.to(self.device))
+        obs = self._to_nhwc(observation.to(self.device), as_obs=True)
         B, H, W, _ = obs.shape
         h, w = self.hidden_hw(H, W)
-        hidden = torch.empty(B, h, w, self.W, dtype=self.act_dtype, device=self.device)
+        hidden = torch.empty(self.act_shape(B, h, w, self.W), dtype=self.act_dtype, device=self.device)
         mean = self._buf("mean", (B, self.W), torch.float32)
         self.represent(obs, hidden, mean)
         _, _, _, pl, vl, _ = self._heads(mean, B, False, True)
@@ -518,11 +577,11 @@ class MuZeroNetwork:
     def recurrent_inference(self, hidden_state: torch.Tensor, action: torch.Tensor) -> NetworkOutput:
         """model.py:340-348.  hidden_state float32 [B, C, h, w]; action integer [B, 1]."""
         hs = self._to_nhwc(hidden_state.to(self.device))
-        B, h, w, _ = hs.shape
+        B, (h, w) = hs.shape[0], hs.shape[-3:-1]
         actions = action.to(self.device).view(B).to(torch.int32).contiguous()
         if B and (int(actions.min()) < 0 or int(actions.max()) >= self.A):    # the kernel gathers by action
             raise IndexError(f"action outside [0, {self.A})")
-        out = torch.empty(B, h, w, self.W, dtype=self.act_dtype, device=self.device)
+        out = torch.empty(self.act_shape(B, h, w, self.W), dtype=self.act_dtype, device=self.device)
         mean = self._buf("mean", (B, self.W), torch.float32)
         self.dynamics(hs, None, 0, actions, out, mean)
         _, _, _, pl, vl, rl = self._heads(mean, B, True, True)

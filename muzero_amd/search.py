@@ -76,7 +76,8 @@ class BatchedMCTS:
         self.trees = DeviceTrees(batch_size, self.A, self.steps + 1, dev, config.pb_c_base, config.pb_c_init,
                                  max_visits=self.sims)
         h, w = network.hidden_hw(*obs_hw)
-        self.pool = torch.empty(self.steps + 1, batch_size, h, w, network.W, dtype=network.act_dtype, device=dev)
+        self.pool = torch.empty(self.steps + 1, batch_size, *network.hidden_shape(h, w), dtype=network.act_dtype,
+                                device=dev)
         self.visits = torch.empty(batch_size, self.A, dtype=torch.int32, device=dev)
         self.root_values = torch.empty(batch_size, dtype=torch.float64, device=dev)
         self.probs = torch.empty(batch_size, self.A, dtype=torch.float64, device=dev)

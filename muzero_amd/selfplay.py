@@ -51,9 +51,9 @@ class SelfPlayWorker:
         self.B = batch_size
         self.A = config.action_space_size
         self.ring = FrameRing(batch_size, frame_stack, obs_hw[0], obs_hw[1], network.device)
-        self.rotating = rotating
-        if rotating:
-            self.ring.enable_rotating(network.act_dtype)   # a move then rewrites 3 of the 96 channels per pixel
+        self.rotating = rotating and not getattr(network, "split", False)   # bf16x3 reads the stacked observation
+        if self.rotating:
+            self.ring.enable_rotating(network.obs_dtype)   # a move then rewrites 3 of the 96 channels per pixel
         self.mcts = BatchedMCTS(config, network, batch_size, num_simulations, wave, obs_hw)
         self._obs = None
         self._obs_shape = (batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack)
@@ -67,7 +67,7 @@ class SelfPlayWorker:
         """Buffer for the stacked observation in the reference's channel order (allocated on first
         use: the rotating path never needs it)."""
         if self._obs is None:
-            self._obs = torch.empty(*self._obs_shape, dtype=self.net.act_dtype, device=self.net.device)
+            self._obs = torch.empty(*self._obs_shape, dtype=self.net.obs_dtype, device=self.net.device)
         return self._obs
 
     def reset(self, frames: torch.Tensor) -> None:
@@ -88,7 +88,7 @@ class SelfPlayWorker:
         if self.rotating:
             obs, newest = self.ring.rotating_observation()
         else:
-            obs, newest = self.ring.observation(self.net.act_dtype, out=self.obs), None
+            obs, newest = self.ring.observation(self.net.obs_dtype, out=self.obs), None
         res: SearchResult = self.mcts.run(obs, self.noise if add_noise else None, rotation=newest)
         actions = select_actions(res.visit_counts, temperature, self.u if temperature != 0 else None)
         return actions, res

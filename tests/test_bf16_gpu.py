@@ -58,7 +58,7 @@ def test_bf16_search_trees_bit_exact_on_their_own_outputs(A, B, wave):
         worker.ring.push(env.step())
     worker.draw_randomness()
     m = worker.mcts
-    obs = worker.ring.observation(net.act_dtype)
+    obs = worker.ring.observation(net.obs_dtype)
     pri0, _ = net.initial_to_pool(obs, m.pool[0])
     pri0 = pri0.clone()
     m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)
@@ -131,7 +131,7 @@ def test_full_size_search_properties_and_sampled_replay(A, B):
     rng = np.random.default_rng(B)
     sample = rng.choice(B, size=24, replace=False)
     idx = torch.from_numpy(sample).cuda()
-    obs = worker.ring.observation(net.act_dtype, out=worker.obs)
+    obs = worker.ring.observation(net.obs_dtype, out=worker.obs)
     pri0, _ = net.initial_to_pool(obs, m.pool[0])
     p0 = pri0[idx].cpu().numpy()
     m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)

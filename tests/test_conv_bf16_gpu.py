@@ -119,3 +119,91 @@ def test_fused_chain_matches_layer_by_layer():
     scale = x.abs().mean().item()
     assert ((got - x).abs() <= 0.02 * x.abs() + 0.02 * scale).all(), (got - x).abs().max().item()
     np.testing.assert_allclose(mean.cpu().numpy(), last_f32.mean(dim=(1, 2)).numpy(), rtol=5e-3, atol=5e-3 * scale)
+
+
+# --------------------------------------------------------------- bf16x3: float32-accurate MFMA kernels
+def _split(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=1).contiguous()
+
+
+def _join(x):
+    return x[:, 0].float() + x[:, 1].float()
+
+
+def _pack_pair(w, chunk):
+    from muzero_amd import mfma
+    return (mfma.pack_weights(w, chunk).cuda(),
+            mfma.pack_weights(w - w.to(torch.bfloat16).float(), chunk).cuda())
+
+
+@pytest.mark.parametrize("name,H,cin,cout,stride", [("stem", 96, 96, 256, 2), ("down0", 48, 256, 128, 2),
+                                                     ("mid", 24, 128, 128, 1), ("down1", 24, 128, 256, 2)])
+def test_x3_conv_shapes_against_torch_fp32(name, H, cin, cout, stride):
+    """mz_conv3x3_bf16x3 against torch's float32 convolution (double precision as the arbiter)."""
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(3)
+    B = 3
+    x = torch.randn(B, H, H, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    HO = (H - 1) // stride + 1
+    res = torch.randn(B, HO, HO, cout, generator=g) if stride == 1 else None
+    chunk, _ = mfma.kernel_info(H, H, cin, cout, stride)
+    wh, wl = _pack_pair(w, chunk)
+    xd, bd = _split(x).cuda(), bias.cuda()
+    rd = _split(res).cuda() if res is not None else None
+    out = torch.empty(B, 2, HO, HO, cout, dtype=torch.bfloat16, device="cuda")
+    _lib.call("mz_conv3x3_bf16x3", _lib.ptr(xd), _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(bd), _lib.ptr(rd), _lib.ptr(out),
+              B, H, H, cin, cout, stride, 1, _lib.current_stream())
+    got = _join(out.cpu())
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), stride, 1)
+    ref = ref.permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.relu(ref)
+    err = (got.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 1e-4 * scale, (name, err, scale)     # measured ~1e-5 of the output range
+
+
+@pytest.mark.parametrize("B,use_slots", [(5, False), (300, True)])
+def test_x3_chain_against_torch_fp32(B, use_slots):
+    """The split-precision chain (dynamics shape: conv + two residual blocks, gather by slot, action
+    vector, spatial mean) against the same layers in torch float64."""
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(11)
+    n_layers, A = 5, 6
+    ws = [torch.randn(256, 256, 3, 3, generator=g) / 48 for _ in range(n_layers)]
+    bs = [torch.randn(256, generator=g) * 0.1 for _ in range(n_layers)]
+    avec = torch.randn(A, 256, generator=g) * 0.2
+    slots = 3 if use_slots else 1
+    pool = torch.randn(slots, B, 12, 12, 256, generator=g)
+    in_slot = torch.randint(0, slots, (B,), generator=g, dtype=torch.int32)
+    actions = torch.randint(0, A, (B,), generator=g, dtype=torch.int32)
+    packs = [_pack_pair(w, 256) for w in ws]
+    biases = [b.cuda() for b in bs]
+    arr = (_lib.ChainLayerX3 * n_layers)()
+    for i in range(n_layers):
+        arr[i] = _lib.ChainLayerX3(packs[i][0].data_ptr(), packs[i][1].data_ptr(), biases[i].data_ptr(), 1,
+                                   1 if i in (2, 4) else 0)
+    pool_d = _split(pool.view(slots * B, 12, 12, 256)).cuda()        # [slots*B, 2, 12, 12, 256]
+    out = torch.empty(B, 2, 12, 12, 256, dtype=torch.bfloat16, device="cuda")
+    mean = torch.empty(B, 256, dtype=torch.float32, device="cuda")
+    avec_d, slot_d, act_d = avec.cuda(), in_slot.cuda(), actions.cuda()
+    _lib.call("mz_conv_chain_bf16x3", _lib.ptr(pool_d), _lib.ptr(slot_d) if use_slots else None, B, arr, n_layers,
+              _lib.ptr(out), _lib.ptr(avec_d), _lib.ptr(act_d), _lib.ptr(mean), B, _lib.current_stream())
+    torch.cuda.synchronize()
+    x = pool[in_slot.long(), torch.arange(B)] if use_slots else pool[0]
+    x = (x + avec[actions.long()][:, None, None, :]).permute(0, 3, 1, 2).double()
+    conv = lambda t, i: torch.nn.functional.conv2d(t, ws[i].double(), bs[i].double(), 1, 1)
+    x = torch.relu(conv(x, 0))
+    for i in (1, 3):
+        y = torch.relu(conv(x, i))
+        x = torch.relu(conv(y, i + 1) + x)
+    ref = x.permute(0, 2, 3, 1)
+    got = _join(out.cpu()).double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-4 * scale
+    assert (mean.cpu().double() - ref.mean(dim=(1, 2))).abs().max().item() <= 2e-4 * scale

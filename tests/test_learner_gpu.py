@@ -218,7 +218,7 @@ def test_selfplay_training_roundtrip():
     loop.save_games(replay, [], cfg.td_steps)
     replay.priorities = list(plain.priorities[:0]) + [1.0] * len(replay.priorities)     # undo the priority update
     np.random.seed(0)
-    obs = worker.ring.observation(net.act_dtype).permute(0, 3, 1, 2).float()
+    obs = worker.ring.observation(net.obs_dtype).permute(0, 3, 1, 2).float()
     before = net.initial_inference(obs).policy_logits.clone()
     metrics = loop.train_steps(learner, replay, 6)
     assert all(np.isfinite(m["total_loss"]) for m in metrics)

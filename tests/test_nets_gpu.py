@@ -26,8 +26,11 @@ def test_small_config_network_matches_reference_fixture():
     assert o0.reward is None
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("A", [6, 18])
-def test_full_size_network_fp32_matches_reference_fixture(A):
+def test_full_size_network_fp32_matches_reference_fixture(A, precision):
+    """Both float32-accurate precisions against the reference's own outputs: "fp32" (vector-unit fmaf
+    kernels) and "bf16x3" (three bf16 MFMAs per product on (hi, lo) pairs), same 1e-3 bound."""
     from muzero_amd.network import MuZeroNetwork
     from muzero_amd.prep import prepare_observation
     from oracle import nets as onets
@@ -36,7 +39,7 @@ def test_full_size_network_fp32_matches_reference_fixture(A):
     ref = onets.Net(full_cfg(A)).eval()
     onets.randomize_bn(ref, seed=1)
     assert onets.state_digest(ref) == str(g[f"digest_bn_A{A}"])
-    net = MuZeroNetwork(full_cfg(A), precision="fp32", state_dict=ref.state_dict())
+    net = MuZeroNetwork(full_cfg(A), precision=precision, state_dict=ref.state_dict())
     frames = np.random.default_rng(1234).integers(0, 256, size=(2, 96, 96, 96), dtype=np.uint8)
     obs = prepare_observation(torch.from_numpy(frames))
     act = torch.tensor([[1], [A - 1]])
@@ -44,7 +47,11 @@ def test_full_size_network_fp32_matches_reference_fixture(A):
     o1 = net.recurrent_inference(o0.hidden_state, act)
     o2 = net.recurrent_inference(o1.hidden_state, act.flip(0))
     torch.cuda.synchronize()
-    chk = lambda got, key: np.testing.assert_allclose(got.cpu().numpy(), g[f"A{A}_{key}"], err_msg=key, **TOL)
+    def chk(got, key):
+        want = g[f"A{A}_{key}"]
+        err = np.abs(got.cpu().numpy() - want) / (TOL["atol"] + TOL["rtol"] * np.abs(want))
+        print(f"{precision} A={A} {key}: worst error {err.max():.3f} of the bound")
+        np.testing.assert_allclose(got.cpu().numpy(), want, err_msg=key, **TOL)
     chk(o0.hidden_state[:1], "h0"); chk(o0.policy_logits, "p0"); chk(o0.value, "v0")
     chk(o1.hidden_state[:1], "h1"); chk(o1.policy_logits, "p1"); chk(o1.value, "v1"); chk(o1.reward, "r1")
     chk(o2.policy_logits, "p2"); chk(o2.value, "v2"); chk(o2.reward, "r2")

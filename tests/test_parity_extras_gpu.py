@@ -64,7 +64,7 @@ def search_both(A, B, sims, precisions):
     for precision in precisions:
         net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
         m = BatchedMCTS(cfg, net, B, sims)
-        r = m.run(ring.observation(net.act_dtype), noise)
+        r = m.run(ring.observation(net.obs_dtype), noise)
         m.check_status()
         res[precision] = (r.visit_counts.cpu().numpy().copy(), r.root_values.cpu().numpy().copy())
         del m, net

@@ -1,4 +1,4 @@
-"""End-to-end search on the device (fp32 networks) against the CPU oracle."""
+"""End-to-end search on the device (float32-accurate networks: fp32 and bf16x3) against the CPU oracle."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +8,7 @@ from tests.test_oracle_golden import full_cfg
 pytestmark = pytest.mark.gpu
 
 
-def _setup(A, seed=0):
+def _setup(A, seed=0, precision="fp32"):
     from muzero_amd.network import MuZeroNetwork
     from oracle import nets as onets
     cfg = full_cfg(A)
@@ -18,7 +18,7 @@ def _setup(A, seed=0):
     torch.manual_seed(seed)
     ref = onets.Net(cfg).eval()
     onets.randomize_bn(ref, seed=1)
-    net = MuZeroNetwork(cfg, precision="fp32", state_dict=ref.state_dict())
+    net = MuZeroNetwork(cfg, precision=precision, state_dict=ref.state_dict())
     return cfg, ref, net
 
 
@@ -38,14 +38,17 @@ def _replay_with_device_outputs(trees_log, priors0, noise, sims, wave, cfg):
     return root, bounds
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("A,wave,noisy", [(6, 1, True), (18, 1, False), (6, 5, True)])
-def test_batched_search_matches_oracle(A, wave, noisy):
+def test_batched_search_matches_oracle(A, wave, noisy, precision):
+    """fp32: exact float32 kernels on the vector units; bf16x3: the float32-accurate matrix-core path.
+    Both are held to the same 1e-3 bound against the CPU oracle."""
     from muzero_amd.prep import FrameRing
     from muzero_amd.search import BatchedMCTS
     from oracle import nets as onets
     from oracle import prep as oprep
     from oracle import tree as otree
-    cfg, ref, net = _setup(A)
+    cfg, ref, net = _setup(A, precision=precision)
     B, sims = 4, 50
     rng = np.random.default_rng(1234)
     frames = rng.integers(0, 256, size=(40, B, 96, 96, 3), dtype=np.uint8)

@@ -32,7 +32,7 @@ res = {}
 for precision in ("fp32", "bf16"):
     net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
     m = BatchedMCTS(cfg, net, B, sims)
-    r = m.run(ring.observation(net.act_dtype), noise)
+    r = m.run(ring.observation(net.obs_dtype), noise)
     res[precision] = (r.visit_counts.cpu().numpy().copy(), r.root_values.cpu().numpy().copy())
     del m, net
 v32, q32 = res["fp32"]
