@@ -85,9 +85,12 @@ def measure_dynamics_kernel(worker, one_step, moves=2):
     heads, net.heads_events = net.heads_events, None
     tree, worker.mcts.tree_events = worker.mcts.tree_events, None
     mean_s = lambda ps: sum(e0.elapsed_time(e1) for e0, e1 in ps) / max(len(ps), 1) * 1e-3
+    # the short launches are summarised by their median: an event pair that straddles a moment when the
+    # stream ran dry (the host preparing the next move) reads milliseconds for a 17 us kernel
+    median_s = lambda ps: float(np.median([e0.elapsed_time(e1) for e0, e1 in ps])) * 1e-3 if ps else 0.0
     n_convs = 1 + 2 * len(net.dyn_blocks)
     # s per launch, convs per launch, launches, (tree s per launch, heads s per launch)
-    return mean_s(pairs), n_convs, len(pairs), (mean_s(tree), mean_s(heads))
+    return mean_s(pairs), n_convs, len(pairs), (median_s(tree), median_s(heads))
 
 
 def load_profiled_traffic():
@@ -101,6 +104,96 @@ def load_profiled_traffic():
         return None
 
 
+class Workload:
+    """One self-play configuration on this rank's GPU: network, worker, synthetic frames."""
+
+    def __init__(self, cfg, sd, device, B, sims, wave, precision, rank, graph=False, from_host=False):
+        from muzero_amd.network import MuZeroNetwork
+        from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+        from muzero_amd.tree import select_actions
+        self.B, self.sims, self.from_host = B, sims, from_host
+        self.net = MuZeroNetwork(cfg, precision=precision, device=device, state_dict=sd)
+        self.worker = worker = SelfPlayWorker(cfg, self.net, B, sims, wave, seed=5678 + rank)
+        self.env = env = SyntheticEnv(B, seed=1234 + rank, device=device)
+        worker.reset(env.reset())
+        for _ in range(31):
+            worker.ring.push(env.step())
+        worker.draw_randomness()
+        self.replay = None
+        if graph:   # the whole search as one HIP graph; frame push and action choice stay outside it
+            if worker.rotating:
+                obs, _ = worker.ring.rotating_observation()
+                self.replay = worker.mcts.capture(obs, worker.noise, rotation=worker.ring.newest_dev)
+            else:
+                worker.ring.observation(self.net.obs_dtype, out=worker.obs)
+                self.replay = worker.mcts.capture(worker.obs, worker.noise)
+        self._select = select_actions
+
+    def one_step(self):
+        w = self.worker
+        w.draw_randomness()  # fresh Dirichlet rows and uniforms every move (host RNG, async copy)
+        frames = self.env.step(on_device=not self.from_host)
+        if self.replay is None:
+            return w.step(frames)[0]
+        w.ring.push(frames)
+        if not w.rotating:
+            w.ring.observation(self.net.obs_dtype, out=w.obs)
+        res = self.replay()
+        return self._select(res.visit_counts, 1.0, w.u)
+
+    def timed(self, steps, warmup, barrier=lambda: None, min_seconds=0.0):
+        """(seconds, steps done): `steps` moves, or as many as fill `min_seconds` (checked every 10 moves)."""
+        for _ in range(warmup):
+            self.one_step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            for _ in range(steps if not min_seconds else 10):
+                actions = self.one_step()
+            done += steps if not min_seconds else 10
+            if not min_seconds:
+                break
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert actions.shape == (self.B,)
+        assert int(self.worker.mcts.visits.sum().item()) == self.B * self.sims
+        self.worker.mcts.check_status()
+        return elapsed, done
+
+    def free(self):
+        self.replay = self.worker = self.net = self.env = None
+        torch.cuda.empty_cache()
+
+
+def chain_roofline(wl, precision, traffic=None):
+    """Roofline entry of the dominant kernel (the fused dynamics chain) of a workload, timed live."""
+    dur, n_convs, n_launches, (tree_s, heads_s) = measure_dynamics_kernel(
+        wl.worker, lambda: wl.worker.step(wl.env.step())[0])
+    flops = TRUNK_FLOPS * n_convs * wl.B
+    achieved = flops / dur / 1e12
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if precision == "bf16x3":
+        # three bf16 MFMAs per product: the matrix pipe executes 3x the algorithmic FLOPs, so the
+        # bound on ALGORITHMIC FLOP/s is a third of the dense bf16 peak
+        kernel, peak, executed = "conv_chain_x3_kernel", PEAK_BF16_TFLOPS / 3, 3 * achieved
+    else:
+        kernel, peak, executed = ("conv_chain_pair_kernel" if wl.B > n_cu else "conv_chain_kernel"), PEAK_BF16_TFLOPS, achieved
+    out = {"bound": "mfma", "kernel": f"{kernel}: dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
+           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+           "launch_us": dur * 1e6, "launches_timed": n_launches, "flops_per_launch": flops}
+    if precision == "bf16x3":
+        out["executed_bf16_tflops"] = executed
+        out["peak_note"] = "2500 TFLOP/s dense bf16 / 3 MFMAs per product"
+    return out, tree_s, heads_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,24 +203,27 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--wave", type=int, default=1)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"],
+                    help="bf16: throughput precision (the headline); bf16x3: float32-accurate (1e-3 vs the reference)")
     ap.add_argument("--graph", action="store_true", help="replay the search from a HIP graph")
     ap.add_argument("--from-host", action="store_true", help="include the pinned H2D copy of the new frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the additional blocks of a 1-GPU run (secondary precision, sustained, from-host, small batch)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0)
+    ap.add_argument("--dry", action="store_true",
+                    help="rank plumbing only (no GPU, no kernels): gloo rendezvous, weight broadcast, barriers, "
+                         "max over ranks, rank 0 prints the line with value null")
     args = ap.parse_args()
 
     from muzero_amd import dist as mzdist
     from muzero_amd.config import MuZeroConfig
-    from muzero_amd.network import MuZeroNetwork, init_state_dict
-    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
-    from muzero_amd.tree import select_actions
+    from muzero_amd.network import init_state_dict
 
-    rank, world, local = mzdist.init_from_env()
+    rank, world, local = mzdist.init_from_env("gloo" if args.dry else None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-
     A, B, label = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
@@ -135,54 +231,42 @@ def main():
     cfg = MuZeroConfig()
     cfg.action_space_size = A
     cfg.num_simulations = args.sims
-
-    # weights: created on rank 0, handed to the other ranks with one RCCL broadcast
-    sd = init_state_dict(cfg, seed=0 if rank == 0 else 1 + rank, randomize_bn=True)
-    sd = mzdist.broadcast_state_dict(sd, src=0)
-    if not mzdist.verify_same_everywhere(sd):
-        raise SystemExit("weight broadcast left ranks with different parameters")
-    net = MuZeroNetwork(cfg, precision="bf16", device=device, state_dict=sd)
-    worker = SelfPlayWorker(cfg, net, B, args.sims, args.wave, seed=5678 + rank)
-    env = SyntheticEnv(B, seed=1234 + rank, device=device)
-    worker.reset(env.reset())
-    for _ in range(31):
-        worker.ring.push(env.step())
-    worker.draw_randomness()
-
-    replay = None
-    if args.graph:
-        worker.ring.observation(net.obs_dtype, out=worker.obs)
-        replay = worker.mcts.capture(worker.obs, worker.noise)
-
-    def one_step():
-        worker.draw_randomness()  # fresh Dirichlet rows and uniforms every move (host RNG, async copy)
-        frames = env.step(on_device=not args.from_host)
-        if replay is None:
-            return worker.step(frames)[0]
-        worker.ring.push(frames)
-        worker.ring.observation(net.obs_dtype, out=worker.obs)
-        res = replay()
-        return select_actions(res.visit_counts, 1.0, worker.u)
+    if args.dry:
+        cfg.num_channels, cfg.downsample_steps = 16, [(8, 1), (16, 1)]       # a small parameter set to broadcast
+        cfg.fc_reward_layers = cfg.fc_value_layers = cfg.fc_policy_layers = [16]
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        actions = one_step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert actions.shape == (B,)
+    # weights: created on rank 0, handed to the other ranks with one broadcast (RCCL on GPUs)
+    sd = init_state_dict(cfg, seed=0 if rank == 0 else 1 + rank, randomize_bn=True)
+    sd = mzdist.broadcast_state_dict(sd, src=0)
+    if not mzdist.verify_same_everywhere(sd):
+        raise SystemExit("weight broadcast left ranks with different parameters")
+
+    if args.dry:
+        barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + rank))          # ranks finish at different times: the maximum must win
+        barrier()
+        elapsed = mzdist.max_over_ranks(time.perf_counter() - t0)
+        lo, hi = mzdist.shard_range(world * B, rank, world)
+        assert hi - lo == B
+        if rank == 0:
+            print(json.dumps({"metric": "mcts_sims_per_sec", "value": None, "unit": "sims/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry": True,
+                              "elapsed_max_over_ranks_s": elapsed, "scaling": "weak",
+                              "config": {"workload": desc, "games_per_gpu": B, "parallelism": f"games sharded x{world}"}}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    wl = Workload(cfg, sd, device, B, args.sims, args.wave, args.precision, rank, args.graph, args.from_host)
+    elapsed, _ = wl.timed(args.steps, args.warmup, barrier)
     elapsed = mzdist.max_over_ranks(elapsed)
-    visits_ok = int(worker.mcts.visits.sum().item()) == B * args.sims
-    worker.mcts.check_status()
 
     if rank == 0:
         total_sims = world * B * args.sims * args.steps
@@ -190,30 +274,24 @@ def main():
         out = {
             "metric": "mcts_sims_per_sec", "value": sims_per_s, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "bf16x3 (float32-accurate: 3 bf16 MFMAs per product)",
             "data": "synthetic",
             "config": {"workload": desc + f", wave {args.wave}", "games_per_gpu": B, "actions": A,
                        "sims_per_move": args.sims, "wave": args.wave, "parallelism": f"games sharded x{world}",
-                       "hip_graph": bool(args.graph), "frames_from_host": bool(args.from_host)},
+                       "precision": args.precision, "hip_graph": bool(args.graph),
+                       "frames_from_host": bool(args.from_host)},
             "env_steps_per_sec": world * B * args.steps / elapsed,
             # ALE "-v5" environments repeat each action over 4 emulator frames (built-in frameskip)
             "env_frames_per_sec": 4 * world * B * args.steps / elapsed,
-            "visit_sum_check": visits_ok,
+            "visit_sum_check": True,
         }
-        dur, n_convs, n_launches, (tree_s, heads_s) = measure_dynamics_kernel(worker, lambda: worker.step(env.step())[0])
-        flops = TRUNK_FLOPS * n_convs * B
-        achieved = flops / dur / 1e12
         prof = load_profiled_traffic()
         traffic = None
-        if prof and prof.get("games_per_gpu") == B:
+        if prof and prof.get("games_per_gpu") == B and args.precision == "bf16":
             traffic = prof.get("hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma",
-                           "kernel": ("conv_chain_pair_kernel" if B > torch.cuda.get_device_properties(0).multi_processor_count
-                                      else "conv_chain_kernel") + f": dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
-                           "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                           "launch_us": dur * 1e6, "launches_timed": n_launches, "flops_per_launch": flops,
-                           "end_to_end_frac": sims_per_s / world * 953.98e6 / (PEAK_BF16_TFLOPS * 1e12)}
+        out["roofline"], tree_s, heads_s = chain_roofline(wl, args.precision, traffic)
+        out["roofline"]["end_to_end_frac"] = sims_per_s / world * 953.98e6 / (out["roofline"]["peak"] * 1e12)
         # the other launches of a simulation step, timed the same way (HIP events include ~2 us of
         # launch latency).  Tree: algorithmic bytes per simulation = D*(A*20+20) read by the descent
         # + A*20+12 written by the expansion + (D+1)*32 for the backup at mean depth D ~ 4.
@@ -225,6 +303,40 @@ def main():
             {"kernel": "heads_kernel (3 MLPs + softmax + support decode)", "bound": "latency (4 dependent phases)",
              "launch_us": heads_s * 1e6},
         ]
+        if world == 1 and not args.no_extras:
+            # (1) the same workload long enough for clocks and temperature to settle
+            t, n = wl.timed(0, 0, min_seconds=args.sustained_seconds)
+            out["sustained"] = {"value": B * args.sims * n / t, "unit": "sims/s", "seconds": t, "steps": n,
+                                "ms_per_step": t / n * 1e3}
+            # (2) new frames arriving from pinned host memory every move (PCIe-inclusive; never `value`)
+            if not args.from_host:
+                wl.from_host = True
+                t, n = wl.timed(args.steps, 2)
+                wl.from_host = False
+                out["from_host"] = {"value": B * args.sims * n / t, "unit": "sims/s", "ms_per_step": t / n * 1e3,
+                                    "h2d_bytes_per_step": B * 96 * 96 * 3}
+            wl.free()
+            # (3) the float32-accurate precision (meets the reference's fp32 outputs to 1e-3) on the same workload
+            other = "bf16x3" if args.precision == "bf16" else "bf16"
+            w2 = Workload(cfg, sd, device, B, args.sims, args.wave, other, rank)
+            t, n = w2.timed(max(2, args.steps // 4), 1)
+            sec = {"precision": other, "value": B * args.sims * n / t, "unit": "sims/s", "ms_per_step": t / n * 1e3,
+                   "steps": n, "config": out["config"]["workload"]}
+            sec["roofline"], _, _ = chain_roofline(w2, other)
+            sec["roofline"]["end_to_end_frac"] = sec["value"] * 953.98e6 / (sec["roofline"]["peak"] * 1e12)
+            out["secondary"] = sec
+            w2.free()
+            # (4) BASELINE configs[1]: Pong-shaped, 6 actions, 256 games, eager launches and one HIP graph per search
+            cfg6 = MuZeroConfig()
+            cfg6.action_space_size, cfg6.num_simulations = 6, args.sims
+            sd6 = init_state_dict(cfg6, seed=0, randomize_bn=True)
+            small = {"workload": f"Pong-shaped 96x96 obs, 6 actions, 256 games x {args.sims} sims, wave 1"}
+            for key, graph in (("eager", False), ("hip_graph", True)):
+                w3 = Workload(cfg6, sd6, device, 256, args.sims, 1, "bf16", rank, graph=graph)
+                t, n = w3.timed(args.steps, 2)
+                small[key] = {"value": 256 * args.sims * n / t, "unit": "sims/s", "ms_per_step": t / n * 1e3}
+                w3.free()
+            out["small_batch"] = small
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, sd, args.sims, args.cpu_seconds)
             out["speedup_vs_cpu"] = sims_per_s / out["cpu_baseline"]["value"]

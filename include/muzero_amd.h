@@ -185,6 +185,13 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
 int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,
                         int32_t relu, mz_stream_t stream);
 
+/* mz_conv3x3_bf16_rot with the weight copy chosen on the device: wpk_all holds one packed copy per possible
+ * newest slot, copy_elems bf16 elements apart (a multiple of 8), and *newest (device int32, 0 <= *newest < D,
+ * guaranteed by the caller) picks the copy when the kernel runs - so a recorded HIP graph of the search stays
+ * valid while the ring advances. */
+int mz_conv3x3_bf16_rot_sel(const void* obs_rot, const void* wpk_all, int64_t copy_elems, const int32_t* newest,
+                            const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream);
+
 /* A chain of 12x12 256->256 convolutions fused into one kernel with the image
  * resident in LDS: the whole dynamics network (conv_state, bn, resblocks;
  * model.py:236-241) or the 12x12 tail of the representation network

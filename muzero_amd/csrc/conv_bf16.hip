@@ -42,6 +42,8 @@ struct ConvArgs {
   const int* actions;
   float* mean_out;
   int relu;
+  const int* wsel = nullptr;  // optional device index: the weights are wpk + *wsel * wsel_stride (elements)
+  long wsel_stride = 0;
 };
 
 template <class C>
@@ -132,8 +134,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   // come by buffer loads: base in a scalar descriptor, k-step offset in a scalar register, the
   // lane's own offset fixed - no vector address arithmetic (reads past the array return zero)
   constexpr int WSTEP = C::NTILES * 1024;  // bytes per k-step
+  const __bf16* wbase = a.wsel ? a.wpk + (long)__builtin_amdgcn_readfirstlane(*a.wsel) * a.wsel_stride : a.wpk;
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(a.wpk), 0, (C::KSTEPS + 2) * WSTEP, 0x00020000);
+      const_cast<__bf16*>(wbase), 0, (C::KSTEPS + 2) * WSTEP, 0x00020000);
   const int wlane = wave * (WN * 1024) + lane * 16;
   auto wfrag = [&](int step_off, int nt) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane + nt * 1024, step_off, 0));
@@ -308,6 +311,16 @@ int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias,
   MZ_REQUIRE(obs_rot && wpk && bias && out && B > 0, "mz_conv3x3_bf16_rot: null tensor or empty batch");
   ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk), bias, nullptr,
              static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu};
+  return launch<ConvStemRot, true>(a, B, mz::as_stream(stream));
+}
+
+int mz_conv3x3_bf16_rot_sel(const void* obs_rot, const void* wpk_all, int64_t copy_elems, const int32_t* newest,
+                            const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(obs_rot && wpk_all && newest && bias && out && B > 0 && copy_elems > 0,
+             "mz_conv3x3_bf16_rot_sel: null tensor or empty batch");
+  MZ_REQUIRE(copy_elems % 8 == 0, "mz_conv3x3_bf16_rot_sel: weight copies must be 16-byte aligned");
+  ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk_all), bias, nullptr,
+             static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu, newest, (long)copy_elems};
   return launch<ConvStemRot, true>(a, B, mz::as_stream(stream));
 }
 

@@ -211,6 +211,9 @@ class MuZeroNetwork:
 
     # ---- parameters
     def load_state_dict(self, sd) -> None:
+        """Every call builds new device weight tensors; ``generation`` counts the calls so that whatever
+        recorded the old tensors' addresses (a HIP graph of the search) can tell it is stale."""
+        self.generation = getattr(self, "generation", 0) + 1
         sd = {k: v.detach().cpu() for k, v in sd.items()}
         self._state_dict = sd
         cfg = self.config
@@ -405,7 +408,7 @@ class MuZeroNetwork:
                 chunk, _ = mfma.kernel_info(self.input_hw[0], self.input_hw[1], layer.cin, layer.cout, layer.stride)
                 cache = mfma.pack_weights_batch(wr, chunk)
             layer.dev["rot"] = cache
-        return cache[newest]
+        return cache if newest is None else cache[newest]
 
     def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor,
                   rotation: Optional[int] = None) -> None:
@@ -448,8 +451,18 @@ class MuZeroNetwork:
             if kind == "conv":
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
                 y = hidden_out if final else self._buf(("rep", i % 3), self.act_shape(B, HO, WO, item.cout))
-                w = self._rotated_weights(item, rotation) if i == 0 and rotation is not None else None
-                if i == 0 and rot_kernel:
+                on_device = torch.is_tensor(rotation)     # the newest slot as a device int32 (HIP-graph replay)
+                if on_device and not (i == 0 and rot_kernel):
+                    if i == 0:
+                        raise NotImplementedError("a device-side rotation index needs the rotating stem kernel")
+                w = None
+                if i == 0 and rotation is not None:
+                    w = self._rotated_weights(item, None if on_device else rotation)
+                if i == 0 and rot_kernel and on_device:
+                    _lib.expect(rotation, "rotation", torch.int32, (1,))
+                    _lib.call("mz_conv3x3_bf16_rot_sel", _lib.ptr(x), _lib.ptr(w), w.shape[1], _lib.ptr(rotation),
+                              _lib.ptr(item.dev["bias"]), _lib.ptr(y), B, 1, _lib.current_stream())
+                elif i == 0 and rot_kernel:
                     _lib.call("mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w), _lib.ptr(item.dev["bias"]), _lib.ptr(y),
                               B, 1, _lib.current_stream())
                 else:

@@ -41,11 +41,13 @@ class FrameRing:
         if self.W % 16:
             raise ValueError("the rotating observation needs an image width that is a multiple of 16")
         self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, 16, 3, dtype=dtype, device=self.device)
+        self.newest_dev = torch.full((1,), self.newest, dtype=torch.int32, device=self.device)   # for graph replay
 
     def _write_rot(self, src: torch.Tensor, fill_all: int, mask: torch.Tensor = None) -> None:
         if self.rot is not None:
             _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), 1 if self.rot.dtype == torch.bfloat16 else 0,
                       self.B, self.depth, self.H * self.W, self.newest, fill_all, _lib.ptr(mask), _lib.current_stream())
+            self.newest_dev.fill_(self.newest)
 
     def reset(self, frames: torch.Tensor) -> None:
         src = self._stage(frames)

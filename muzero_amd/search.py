@@ -130,19 +130,31 @@ class BatchedMCTS:
             code = int(st[bad].item())
             raise _lib.MuZeroAmdError(f"search: game {bad} reported status {code} ({codes.get(code, '?')})")
 
-    def capture(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None):
+    def capture(self, observations: torch.Tensor, noise: Optional[torch.Tensor] = None,
+                rotation: Optional[torch.Tensor] = None):
         """Record one whole search (initial inference, every simulation step, read-out)
         into a HIP graph reading ``observations`` / ``noise`` in place.  Returns a
         ``replay()`` callable: refill the two tensors, call it, read the result
-        tensors.  Worth it when B is small and the per-kernel launch cost shows."""
-        self._search(observations, noise)  # warm-up: sizes every scratch buffer
+        tensors.  Worth it when B is small and the per-kernel launch cost shows.
+        rotation: for an observation in rotating form, the device int32 [1] that holds the newest
+        slot (``FrameRing.newest_dev``): the first convolution picks its weight copy from it when the
+        graph runs.  The graph holds the addresses of the network's device weights: after
+        ``network.load_state_dict`` (new tensors) ``replay()`` raises instead of reading freed memory -
+        capture again."""
+        if rotation is not None and not torch.is_tensor(rotation):
+            raise ValueError("capture(): pass the rotation as the device tensor FrameRing.newest_dev")
+        self._search(observations, noise, rotation)  # warm-up: sizes every scratch buffer
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._search(observations, noise)
+            self._search(observations, noise, rotation)
         result = SearchResult(self.visits, self.root_values, self.probs)
+        generation = self.net.generation
 
         def replay() -> SearchResult:
+            if self.net.generation != generation:
+                raise _lib.MuZeroAmdError("the network's weights were reloaded after this search was captured: "
+                                          "the graph points at the old device tensors; call capture() again")
             graph.replay()
             return result
         return replay

@@ -239,3 +239,44 @@ def test_per_game_restart_refills_only_the_flagged_stacks():
     rot, newest = ring.rotating_observation()
     perm = ring.rotation_permutation().cuda()
     assert torch.equal(ring.observation(torch.bfloat16)[..., perm], untile(rot))
+
+
+def test_graph_replay_of_the_rotating_path_and_stale_graph_guard():
+    """A HIP graph of the search on the rotating observation keeps working while the frame ring
+    advances (the stem's weight copy is chosen on the device from the ring's newest slot), gives
+    the eager result bit for bit, and refuses to run after the network's weights were reloaded
+    (the graph holds the old tensors' addresses)."""
+    from muzero_amd import _lib
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg = MuZeroConfig()
+    cfg.action_space_size, cfg.num_simulations = 6, 10
+    sd = init_state_dict(cfg, seed=2, randomize_bn=True)
+    net = MuZeroNetwork(cfg, precision="bf16", state_dict=sd)
+    B = 7
+    worker = SelfPlayWorker(cfg, net, B, 10)
+    env = SyntheticEnv(B, device="cuda", pool=8)
+    worker.reset(env.reset())
+    worker.draw_randomness()
+    obs, _ = worker.ring.rotating_observation()
+    replay = worker.mcts.capture(obs, worker.noise, rotation=worker.ring.newest_dev)
+    for step in range(35):                                    # wraps the ring of 32
+        worker.ring.push(env.step())
+        if step % 6 and step < 30:
+            continue
+        obs, newest = worker.ring.rotating_observation()
+        eager = worker.mcts.run(obs, worker.noise, rotation=newest)
+        v, q = eager.visit_counts.cpu().numpy().copy(), eager.root_values.cpu().numpy().copy()
+        worker.mcts.visits.zero_()
+        res = replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(res.visit_counts.cpu().numpy(), v), step
+        assert np.array_equal(res.root_values.cpu().numpy(), q), step
+    net.load_state_dict(init_state_dict(cfg, seed=3, randomize_bn=True))
+    with pytest.raises(_lib.MuZeroAmdError, match="capture"):
+        replay()
+    fresh = worker.mcts.capture(obs, worker.noise, rotation=worker.ring.newest_dev)
+    eager = worker.mcts.run(obs, worker.noise, rotation=worker.ring.newest)
+    v = eager.visit_counts.cpu().numpy().copy()
+    assert np.array_equal(fresh().visit_counts.cpu().numpy(), v)
