@@ -325,6 +325,38 @@ int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, 
                            mz_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Weight hand-over on the device: from the float32 parameters of a state_dict (e.g. views into
+ * the flat buffer a weight broadcast filled) to what the kernels read.  The reference shares one
+ * network object between training and self-play (train.py:155); here the search engine's copy is
+ * refreshed by these calls after every update, without the parameters visiting the host.
+ * ------------------------------------------------------------------ */
+
+/* One 3x3 convolution (+ the BatchNorm behind it, when its four vectors are given: inference form,
+ * model.py:143-175 in eval mode; fold in double as scale = gamma / sqrt(var + eps)):
+ *   mode 0: bf16 fragments in mz_conv3x3_bf16's packing, followed by its two k-steps of zeros;
+ *   mode 1: the same for the residue w - bf16(w) (the lo part of the bf16x3 precision);
+ *   mode 2: float32 [tap][Cin][Cout] (mz_conv3x3_f32).
+ * transpose != 0 packs W'[o][i][tap] = w[i][o][8 - tap], the weights with which a convolution over the
+ * output gradient gives the input gradient (square layers, no BatchNorm).  rot_depth = D > 0 writes D copies
+ * mz_packed_conv_elems(...) elements apart, copy r with input channel j taken from channel
+ * 3*((j/3 - r - 1) mod D) + j%3 (mz_conv3x3_bf16_rot).  bias_out (optional): float [Cout] folded bias.
+ * Results equal the host's torch arithmetic bit for bit. */
+int64_t mz_packed_conv_elems(int32_t Cout, int32_t Cin, int32_t mode);
+int mz_weights_fold_pack(const float* w, const float* conv_bias, const float* bn_weight, const float* bn_bias,
+                         const float* bn_mean, const float* bn_var, double eps, int32_t Cout, int32_t Cin,
+                         int32_t cin_chunk, int32_t mode, int32_t transpose, int32_t rot_depth, void* out,
+                         float* bias_out, mz_stream_t stream);
+
+/* A torch Linear layer (weight [O][K], bias [O]) in the fragment order of mz_head_weights (float32, or bf16 when
+ * bf16 != 0) with the bias zero-padded to a multiple of 16. */
+int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int32_t bf16, void* w_packed,
+                   float* bias_padded, mz_stream_t stream);
+
+/* dynamics.conv_action (1x1, weight [C][A], bias [C]) as the per-action vectors the dynamics kernels add:
+ * out[a][c] = w[c][a] + bias[c] (model.py:231-236). */
+int mz_action_vectors(const float* w, const float* bias, int32_t C, int32_t A, float* out, mz_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * Training side (the callers after the search path).
  * ------------------------------------------------------------------ */
 

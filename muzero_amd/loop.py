@@ -41,7 +41,7 @@ def play_moves(worker: SelfPlayWorker, games: List[GameHistory], env_step: Calla
         worker.draw_randomness()
         actions, res = worker.step(frames, temperature)
         counts = res.visit_counts.cpu().numpy()
-        worker.mcts.check_status()        # e.g. no selectable child under non-finite priors: the reference crashes there
+        worker.check_status()             # e.g. no selectable child under non-finite priors: the reference crashes there
         V.append(res.root_values.cpu().numpy().copy())
         acts = actions.cpu().numpy()
         P.append(counts / np.maximum(counts.sum(1, keepdims=True), 1))
@@ -84,7 +84,7 @@ class _ContinuousGroup:
         """Wait for the search; returns host arrays (actions, root values, visit distributions)."""
         actions, res = self._search
         counts = res.visit_counts.cpu().numpy()
-        self.worker.mcts.check_status()   # the host waits here anyway; trouble in a tree must not reach the replay buffer
+        self.worker.check_status()        # the host waits here anyway; trouble in a tree must not reach the replay buffer
         probs = counts / np.maximum(counts.sum(1, keepdims=True), 1)
         self._last = (actions.cpu().numpy(), res.root_values.cpu().numpy().copy(), probs)
         return self._last[0]
@@ -169,7 +169,7 @@ def evaluate(worker: SelfPlayWorker, first_frames: torch.Tensor, env_step: Calla
     for _ in range(max_moves):
         actions, _ = worker.step(frames, temperature=0, add_noise=False)
         acts = actions.cpu().numpy()
-        worker.mcts.check_status()
+        worker.check_status()
         stepped = env_step(acts)
         frames, rewards = stepped[0], np.asarray(stepped[1], np.float64)
         total += np.where(alive, rewards, 0.0)

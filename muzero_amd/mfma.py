@@ -1,5 +1,6 @@
-"""Host side of the bf16 MFMA convolution (mz_conv3x3_bf16): weight packing into
-MFMA fragment order and the launch wrapper."""
+"""Host side of the bf16 MFMA convolution (mz_conv3x3_bf16): the launch wrapper, and the fragment
+packing written out in torch (``pack_weights``) - the network packs on the device
+(``mz_weights_fold_pack``); the torch form serves tests and tools, and checks the kernel."""
 import ctypes as C
 
 import torch
@@ -12,6 +13,11 @@ def kernel_info(H: int, W: int, cin: int, cout: int, stride: int):
     chunk, whole = C.c_int32(0), C.c_int32(0)
     _lib.call("mz_conv3x3_bf16_info", H, W, cin, cout, stride, C.byref(chunk), C.byref(whole))
     return chunk.value, bool(whole.value)
+
+
+def packed_elems(cout: int, cin: int) -> int:
+    """bf16 elements of one packed 3x3 layer, including the two k-steps of zeros behind the fragments."""
+    return cout * cin * 9 + 2 * (cout // 16) * 512
 
 
 def pack_weights(w: torch.Tensor, chunk: int) -> torch.Tensor:

@@ -124,65 +124,55 @@ def init_state_dict(cfg, seed: int = 0, randomize_bn: bool = False) -> "OrderedD
 
 
 class ConvLayer:
-    """One 3x3 convolution with BatchNorm folded in (float32 master copy)."""
+    """One 3x3 convolution + the BatchNorm behind it, as the kernels see them: shapes and the device
+    buffers (``dev``) holding the folded bias and the weights in the precision's layout."""
 
     def __init__(self, sd, conv: str, bn: str, stride: int):
-        w = sd[conv + ".weight"].double()
-        b = sd[conv + ".bias"].double()
-        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + BN_EPS)
-        self.w = (w * scale.view(-1, 1, 1, 1)).float()                       # [Cout][Cin][3][3]
-        self.b = ((b - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()).float()
-        self.cout, self.cin = self.w.shape[0], self.w.shape[1]
+        w = sd[conv + ".weight"]
+        self.cout, self.cin = int(w.shape[0]), int(w.shape[1])
         self.stride = stride
-        self.name = conv
+        self.name, self.bn = conv, bn
         self.dev: Dict[str, torch.Tensor] = {}
-
-
-def _pack_linear(w: torch.Tensor) -> torch.Tensor:
-    """torch Linear weight [O][K] -> float32 MFMA fragments [ceil(O/16)][K/4][lane = kq*16 + r]
-    holding W[tile*16 + r][4*kstep + kq]; rows beyond O are zero."""
-    O, K = w.shape
-    tiles = (O + 15) // 16
-    wp = torch.zeros(tiles * 16, K, dtype=torch.float32)
-    wp[:O] = w.float()
-    return wp.view(tiles, 16, K // 4, 4).permute(0, 2, 3, 1).contiguous().view(-1)
-
-
-def _pack_linear_bf16(w: torch.Tensor) -> torch.Tensor:
-    """torch Linear weight [O][K] -> bf16 MFMA fragments [ceil(O/16)][K/32][lane = kq*16 + r][8]
-    holding W[tile*16 + r][32*kstep + 8*kq + j]; rows beyond O are zero."""
-    O, K = w.shape
-    tiles = (O + 15) // 16
-    wp = torch.zeros(tiles * 16, K, dtype=torch.float32)
-    wp[:O] = w.float()
-    return wp.to(torch.bfloat16).view(tiles, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
-
-
-class Head:
-    def __init__(self, sd, name: str, device, bf16: bool = False):
-        keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
-        if len(keys) != 2:
-            raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
-        k1, k2 = keys
-        w1, w2 = sd[f"{name}.{k1}.weight"], sd[f"{name}.{k2}.weight"]
-        self.hidden, self.out = w1.shape[0], w2.shape[0]
-        if self.hidden % 16 or w1.shape[1] % 4:
-            raise NotImplementedError(f"{name}: hidden width must be a multiple of 16 and the input of 4")
-        bf16 = bf16 and self.hidden % 32 == 0 and w1.shape[1] % 32 == 0
-        pack = _pack_linear_bf16 if bf16 else _pack_linear
-        self.w1p = pack(w1).to(device)
-        self.b1 = sd[f"{name}.{k1}.bias"].float().contiguous().to(device)
-        self.w2p = pack(w2).to(device)
-        b2 = torch.zeros((self.out + 15) // 16 * 16)
-        b2[:self.out] = sd[f"{name}.{k2}.bias"].float()
-        self.b2 = b2.to(device)
-        self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr(),
-                              1 if bf16 else 0, 0)
 
 
 class _HeadWeights(C.Structure):
     _fields_ = [("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p),
                 ("bf16", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Head:
+    """One fully connected head with a single hidden layer; its weights live in persistent device
+    buffers in MFMA fragment order (``mz_pack_linear`` refills them in place)."""
+
+    def __init__(self, sd, name: str, device, bf16: bool = False):
+        keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
+        if len(keys) != 2:
+            raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
+        self.name, (self.k1, self.k2) = name, keys
+        w1, w2 = sd[f"{name}.{self.k1}.weight"], sd[f"{name}.{self.k2}.weight"]
+        self.hidden, self.out, self.cin = int(w1.shape[0]), int(w2.shape[0]), int(w1.shape[1])
+        if self.hidden % 16 or self.cin % 4:
+            raise NotImplementedError(f"{name}: hidden width must be a multiple of 16 and the input of 4")
+        self.bf16 = bool(bf16 and self.hidden % 32 == 0 and self.cin % 32 == 0)
+        dt = torch.bfloat16 if self.bf16 else torch.float32
+        tiles = (self.out + 15) // 16
+        self.w1p = torch.empty(self.hidden * self.cin, dtype=dt, device=device)
+        self.b1 = torch.empty(self.hidden, dtype=torch.float32, device=device)
+        self.w2p = torch.empty(tiles * 16 * self.hidden, dtype=dt, device=device)
+        self.b2 = torch.empty(tiles * 16, dtype=torch.float32, device=device)
+        self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr(),
+                              1 if self.bf16 else 0, 0)
+
+    def fill(self, dsd) -> None:
+        """dsd: the state_dict as float32 device tensors."""
+        n = self.name
+        w1, b1 = dsd[f"{n}.{self.k1}.weight"], dsd[f"{n}.{self.k1}.bias"]
+        w2, b2 = dsd[f"{n}.{self.k2}.weight"], dsd[f"{n}.{self.k2}.bias"]
+        st = _lib.current_stream()
+        _lib.call("mz_pack_linear", _lib.ptr(w1), _lib.ptr(b1), self.hidden, self.cin, int(self.bf16),
+                  _lib.ptr(self.w1p), _lib.ptr(self.b1), st)
+        _lib.call("mz_pack_linear", _lib.ptr(w2), _lib.ptr(b2), self.out, self.hidden, int(self.bf16),
+                  _lib.ptr(self.w2p), _lib.ptr(self.b2), st)
 
 
 # --------------------------------------------------------------------------- network
@@ -211,11 +201,29 @@ class MuZeroNetwork:
 
     # ---- parameters
     def load_state_dict(self, sd) -> None:
-        """Every call builds new device weight tensors; ``generation`` counts the calls so that whatever
-        recorded the old tensors' addresses (a HIP graph of the search) can tell it is stale."""
-        self.generation = getattr(self, "generation", 0) + 1
-        sd = {k: v.detach().cpu() for k, v in sd.items()}
-        self._state_dict = sd
+        """Take the parameters of a state_dict (the reference's names; host or device tensors).  All
+        arithmetic happens on the device: BatchNorm folding, rounding, fragment packing
+        (``mz_weights_fold_pack``, ``mz_pack_linear``, ``mz_action_vectors``) - device tensors, e.g.
+        the views into a broadcast buffer, never visit the host.  The kernels' weight buffers are
+        allocated by the first call and REFILLED IN PLACE by later calls with the same shapes, so
+        their addresses - in a recorded HIP graph of the search, say - stay valid; ``generation``
+        counts the (re)allocations."""
+        dsd = {k: (v.detach().to(self.device, torch.float32).contiguous() if v.is_floating_point() else v)
+               for k, v in sd.items()}
+        structure = tuple((k, tuple(v.shape)) for k, v in sd.items())
+        if structure != getattr(self, "_structure", None):
+            self._build(dsd)
+            self._structure = structure
+            self.generation = getattr(self, "generation", 0) + 1
+        self._dsd = dsd
+        self._fill()
+
+    def state_dict(self):
+        """The parameters last loaded (host copies, reference names)."""
+        return {k: v.detach().cpu() for k, v in self._dsd.items()}
+
+    def _build(self, sd) -> None:
+        """Layer plan and device buffers for the shapes in ``sd``."""
         cfg = self.config
         rep: List[tuple] = [("conv", ConvLayer(sd, "representation.conv1", "representation.bn1", 2))]
         for i, (_, n) in enumerate(cfg.downsample_steps):
@@ -230,8 +238,7 @@ class MuZeroNetwork:
         self.rep_plan = rep
         self.dyn_first = ConvLayer(sd, "dynamics.conv_state", "dynamics.bn", 1)
         self.dyn_blocks = [self._res(sd, f"dynamics.resblocks.{j}") for j in range(cfg.num_blocks)]
-        wa = sd["dynamics.conv_action.weight"].float()[:, :, 0, 0]          # [W][A]
-        self.action_vec = (wa.t() + sd["dynamics.conv_action.bias"].float()).contiguous().to(self.device)  # [A][W]
+        self.action_vec = torch.empty(self.A, self.W, dtype=torch.float32, device=self.device)     # [A][W]
         hb = self.precision == "bf16"  # heads follow the network's precision
         self.policy = Head(sd, "prediction.policy_head", self.device, hb)
         self.value_head = Head(sd, "prediction.value_head", self.device, hb)
@@ -239,10 +246,50 @@ class MuZeroNetwork:
         if not (self.policy.hidden == self.value_head.hidden == self.reward_head.hidden):
             raise NotImplementedError("the three heads must share one hidden width")
         self._chains = {}
-        self._upload_all()
+        H, W = self.input_hw
+        for kind, item in self.rep_plan:
+            for layer in ([item] if kind == "conv" else item):
+                layer.hw = (H, W)
+                H, W = (H - 1) // layer.stride + 1, (W - 1) // layer.stride + 1
+        for layer in [self.dyn_first] + [l for blk in self.dyn_blocks for l in blk]:
+            layer.hw = (H, W)
+        for layer in self.all_convs():
+            layer.dev["bias"] = torch.empty(layer.cout, dtype=torch.float32, device=self.device)
+            if self.precision == "fp32":
+                layer.chunk = 0
+                layer.dev["w"] = torch.empty(9 * layer.cin * layer.cout, dtype=torch.float32, device=self.device)
+            else:
+                from . import mfma
+                layer.chunk, layer.whole_image = mfma.kernel_info(layer.hw[0], layer.hw[1], layer.cin, layer.cout,
+                                                                  layer.stride)
+                n = mfma.packed_elems(layer.cout, layer.cin)
+                layer.dev["w"] = torch.empty(n, dtype=torch.bfloat16, device=self.device)
+                if self.split:   # the part of the float32 weight its bf16 rounding leaves out
+                    layer.dev["w_lo"] = torch.empty(n, dtype=torch.bfloat16, device=self.device)
 
-    def state_dict(self):
-        return self._state_dict
+    def _fold_pack(self, layer: ConvLayer, mode: int, out: torch.Tensor, bias_out=None, rot_depth: int = 0) -> None:
+        d = self._dsd
+        bn = layer.bn
+        _lib.call("mz_weights_fold_pack", _lib.ptr(d[layer.name + ".weight"]), _lib.ptr(d[layer.name + ".bias"]),
+                  _lib.ptr(d[bn + ".weight"]), _lib.ptr(d[bn + ".bias"]), _lib.ptr(d[bn + ".running_mean"]),
+                  _lib.ptr(d[bn + ".running_var"]), BN_EPS, layer.cout, layer.cin, layer.chunk, mode, 0, rot_depth,
+                  _lib.ptr(out), _lib.ptr(bias_out), _lib.current_stream())
+
+    def _fill(self) -> None:
+        """Device copies of the folded weights in the layout the kernels read, into the existing buffers."""
+        for layer in self.all_convs():
+            self._fold_pack(layer, 2 if self.precision == "fp32" else 0, layer.dev["w"], layer.dev["bias"])
+            if self.split:
+                self._fold_pack(layer, 1, layer.dev["w_lo"])
+            if "rot" in layer.dev:
+                self._fold_pack(layer, 2 if self.precision == "fp32" else 0, layer.dev["rot"], None,
+                                rot_depth=layer.cin // 3)
+        d = self._dsd
+        _lib.call("mz_action_vectors", _lib.ptr(d["dynamics.conv_action.weight"]),
+                  _lib.ptr(d["dynamics.conv_action.bias"]), self.W, self.A, _lib.ptr(self.action_vec),
+                  _lib.current_stream())
+        for head in (self.policy, self.value_head, self.reward_head):
+            head.fill(d)
 
     @staticmethod
     def _res(sd, p):
@@ -254,30 +301,6 @@ class MuZeroNetwork:
         yield self.dyn_first
         for blk in self.dyn_blocks:
             yield from blk
-
-    def _upload_all(self) -> None:
-        """Device copies of the folded weights in the layout the kernels read."""
-        H, W = self.input_hw
-        shapes = []
-        for kind, item in self.rep_plan:
-            for layer in ([item] if kind == "conv" else item):
-                shapes.append((layer, H, W))
-                H, W = (H - 1) // layer.stride + 1, (W - 1) // layer.stride + 1
-        for layer in [self.dyn_first] + [l for blk in self.dyn_blocks for l in blk]:
-            shapes.append((layer, H, W))
-        for layer, h, w in shapes:
-            layer.dev["bias"] = layer.b.contiguous().to(self.device)
-            if self.precision == "fp32":
-                # [Cout][Cin][ky][kx] -> [tap][Cin][Cout]
-                layer.dev["w"] = layer.w.permute(2, 3, 1, 0).reshape(9, layer.cin, layer.cout).contiguous().to(self.device)
-            else:
-                from . import mfma
-                chunk, whole = mfma.kernel_info(h, w, layer.cin, layer.cout, layer.stride)
-                layer.whole_image = whole
-                layer.dev["w"] = mfma.pack_weights(layer.w, chunk).to(self.device)
-                if self.split:   # the part of the float32 weight its bf16 rounding leaves out
-                    rest = layer.w - layer.w.to(torch.bfloat16).float()
-                    layer.dev["w_lo"] = mfma.pack_weights(rest, chunk).to(self.device)
 
     # ---- scratch
     def _buf(self, tag, shape, dtype=None):
@@ -390,24 +413,24 @@ class MuZeroNetwork:
             H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         return H, W
 
-    def _rotated_weights(self, layer: ConvLayer, newest: int) -> torch.Tensor:
+    def _rotated_weights(self, layer: ConvLayer, newest) -> torch.Tensor:
         """Device weights of the first convolution for an observation in rotating form
-        (prep.FrameRing.rotating_observation): input channels permuted to the slot order."""
+        (prep.FrameRing.rotating_observation): input channels permuted to the slot order.  All
+        rotations are packed at once on first use (32 x 0.44 MB for the reference's stem) and
+        refilled by every later load_state_dict.  newest None: the whole [D, packed] table."""
         cache = layer.dev.get("rot")
-        if cache is None:   # all rotations at once, on the device (32 x 0.44 MB for the reference's stem)
-            from .prep import rotation_permutation
+        if cache is None:
             if layer.cin % 3:
                 raise ValueError("rotating observations need 3 channels per frame")
             D = layer.cin // 3
-            perms = torch.stack([rotation_permutation(D, r) for r in range(D)]).to(self.device)   # [D][Cin]
-            wr = layer.w.to(self.device)[:, perms].permute(1, 0, 2, 3, 4)                           # [D][Cout][Cin][3][3]
             if self.precision == "fp32":
-                cache = wr.permute(0, 3, 4, 2, 1).reshape(D, 9, layer.cin, layer.cout).contiguous()
+                cache = torch.empty(D, 9 * layer.cin * layer.cout, dtype=torch.float32, device=self.device)
             else:
                 from . import mfma
-                chunk, _ = mfma.kernel_info(self.input_hw[0], self.input_hw[1], layer.cin, layer.cout, layer.stride)
-                cache = mfma.pack_weights_batch(wr, chunk)
+                cache = torch.empty(D, mfma.packed_elems(layer.cout, layer.cin), dtype=torch.bfloat16,
+                                    device=self.device)
             layer.dev["rot"] = cache
+            self._fold_pack(layer, 2 if self.precision == "fp32" else 0, cache, None, rot_depth=D)
         return cache if newest is None else cache[newest]
 
     def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor,

@@ -138,9 +138,10 @@ class BatchedMCTS:
         tensors.  Worth it when B is small and the per-kernel launch cost shows.
         rotation: for an observation in rotating form, the device int32 [1] that holds the newest
         slot (``FrameRing.newest_dev``): the first convolution picks its weight copy from it when the
-        graph runs.  The graph holds the addresses of the network's device weights: after
-        ``network.load_state_dict`` (new tensors) ``replay()`` raises instead of reading freed memory -
-        capture again."""
+        graph runs.  The graph holds the addresses of the network's device weight buffers.
+        ``network.load_state_dict`` refills those buffers in place, so a later ``replay()`` searches with the
+        new weights; if a load had to allocate new buffers (other shapes), ``replay()`` raises instead of
+        reading freed memory - capture again."""
         if rotation is not None and not torch.is_tensor(rotation):
             raise ValueError("capture(): pass the rotation as the device tensor FrameRing.newest_dev")
         self._search(observations, noise, rotation)  # warm-up: sizes every scratch buffer
@@ -153,8 +154,8 @@ class BatchedMCTS:
 
         def replay() -> SearchResult:
             if self.net.generation != generation:
-                raise _lib.MuZeroAmdError("the network's weights were reloaded after this search was captured: "
-                                          "the graph points at the old device tensors; call capture() again")
+                raise _lib.MuZeroAmdError("the network allocated new weight buffers after this search was captured: "
+                                          "the graph points at the old ones; call capture() again")
             graph.replay()
             return result
         return replay

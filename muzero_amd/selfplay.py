@@ -73,6 +73,10 @@ class SelfPlayWorker:
     def reset(self, frames: torch.Tensor) -> None:
         self.ring.reset(frames)
 
+    def check_status(self) -> None:
+        """Raise if a tree reported trouble in the last search (one small device read-back)."""
+        self.mcts.check_status()
+
     def draw_randomness(self) -> None:
         """Dirichlet rows for the roots and uniforms for the action choice (host RNG)."""
         alpha = getattr(self.config, "root_dirichlet_alpha", 0.3)

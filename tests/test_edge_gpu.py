@@ -244,8 +244,8 @@ def test_per_game_restart_refills_only_the_flagged_stacks():
 def test_graph_replay_of_the_rotating_path_and_stale_graph_guard():
     """A HIP graph of the search on the rotating observation keeps working while the frame ring
     advances (the stem's weight copy is chosen on the device from the ring's newest slot), gives
-    the eager result bit for bit, and refuses to run after the network's weights were reloaded
-    (the graph holds the old tensors' addresses)."""
+    the eager result bit for bit, follows weights reloaded in place, and refuses to run once the
+    network had to allocate new weight buffers (the graph holds the old addresses)."""
     from muzero_amd import _lib
     from muzero_amd.config import MuZeroConfig
     from muzero_amd.network import MuZeroNetwork, init_state_dict
@@ -273,7 +273,17 @@ def test_graph_replay_of_the_rotating_path_and_stale_graph_guard():
         torch.cuda.synchronize()
         assert np.array_equal(res.visit_counts.cpu().numpy(), v), step
         assert np.array_equal(res.root_values.cpu().numpy(), q), step
+    # new weights of the same shapes are written into the same device buffers: the graph stays valid
+    # and computes with them
     net.load_state_dict(init_state_dict(cfg, seed=3, randomize_bn=True))
+    eager = worker.mcts.run(obs, worker.noise, rotation=worker.ring.newest)
+    v, q = eager.visit_counts.cpu().numpy().copy(), eager.root_values.cpu().numpy().copy()
+    worker.mcts.visits.zero_()
+    res = replay()
+    assert np.array_equal(res.visit_counts.cpu().numpy(), v) and np.array_equal(res.root_values.cpu().numpy(), q)
+    # a load that has to allocate new buffers (here forced) makes the old graph refuse to run
+    net._structure = None
+    net.load_state_dict(init_state_dict(cfg, seed=4, randomize_bn=True))
     with pytest.raises(_lib.MuZeroAmdError, match="capture"):
         replay()
     fresh = worker.mcts.capture(obs, worker.noise, rotation=worker.ring.newest_dev)

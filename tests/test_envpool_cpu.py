@@ -78,6 +78,9 @@ def test_play_moves_records_like_the_reference_loop():
         def draw_randomness(self):
             pass
 
+        def check_status(self):
+            pass
+
         def step(self, frames, temperature):
             self.t += 1
             return torch.full((B,), self.t % A, dtype=torch.int32), Res(self.t)
@@ -142,6 +145,9 @@ def test_play_continuous_hands_over_finished_games_and_restarts_them():
         def draw_randomness(self):
             pass
 
+        def check_status(self):
+            pass
+
         def step(self, frames, temperature, restarted=None):
             self.t += 1
             self.masks.append(None if restarted is None else restarted.tolist())
@@ -188,6 +194,9 @@ def test_play_pipelined_matches_two_independent_continuous_runs():
             pass
 
         def draw_randomness(self):
+            pass
+
+        def check_status(self):
             pass
 
         def step(self, frames, temperature, restarted=None):
