@@ -48,7 +48,7 @@ def cpu_baseline(cfg, sd, sims, budget_s=20.0):
     threads = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else int(os.environ["OMP_NUM_THREADS"])
     torch.set_num_threads(threads)
     net = onets.Net(cfg).eval()
-    net.load_state_dict(sd, strict=True)
+    net.load_state_dict({k: v.cpu() for k, v in sd.items()}, strict=True)
     infer = onets.make_infer(net)
     rng = np.random.default_rng(1234)
     done, t_search = 0, 0.0

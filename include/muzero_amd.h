@@ -356,6 +356,17 @@ int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int3
  * out[a][c] = w[c][a] + bias[c] (model.py:231-236). */
 int mz_action_vectors(const float* w, const float* bias, int32_t C, int32_t A, float* out, mz_stream_t stream);
 
+/* The weight broadcast itself, RCCL over xGMI behind the C ABI (the one collective of the path; the
+ * reference shares one network object in one process, train.py:155).  RCCL is bound at run time, preferring the
+ * copy already loaded in the process.  One rank calls mz_comm_unique_id (128 bytes) and hands the bytes to the
+ * others by any side channel; every rank then calls mz_comm_init with its rank (its GPU current) and later
+ * mz_comm_bcast_weights on the flat parameter buffer: in place, `bytes` bytes from rank `root` to all, on the
+ * given stream.  MZ_E_STATE when RCCL cannot be loaded. */
+int mz_comm_unique_id(void* id128);
+int mz_comm_init(const void* id128, int32_t rank, int32_t world, void** comm_out);
+int mz_comm_bcast_weights(void* comm, void* buffer, int64_t bytes, int32_t root, mz_stream_t stream);
+int mz_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------ *
  * Training side (the callers after the search path).
  * ------------------------------------------------------------------ */

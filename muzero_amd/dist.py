@@ -52,11 +52,61 @@ def state_checksum(sd) -> str:
     return h.hexdigest()
 
 
+class WeightComm:
+    """The weight broadcast through this library's own RCCL binding (``mz_comm_*`` in the C ABI)
+    instead of torch.distributed's.  The 128-byte RCCL id travels over the existing process group
+    (any backend) once; afterwards ``broadcast`` is one in-place RCCL broadcast of a flat device
+    buffer on the current stream."""
+
+    def __init__(self):
+        import ctypes as C
+        from . import _lib
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            _lib.call("mz_comm_unique_id", ident)
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        handle = C.c_void_p()
+        _lib.call("mz_comm_init", box[0], rank, world, C.byref(handle))
+        self._lib, self.handle, self.rank, self.world = _lib, handle, rank, world
+
+    def broadcast(self, flat: torch.Tensor, src: int = 0) -> None:
+        if not flat.is_cuda or not flat.is_contiguous():
+            raise ValueError("WeightComm.broadcast takes a contiguous device tensor")
+        self._lib.call("mz_comm_bcast_weights", self.handle, self._lib.ptr(flat), flat.numel() * flat.element_size(), src,
+                       self._lib.current_stream())
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.call("mz_comm_destroy", self.handle)
+            self.handle = None
+
+
+_weight_comm = None
+
+
+def _flat_broadcast(flat: torch.Tensor, src: int) -> None:
+    """One broadcast of a flat buffer: torch.distributed's (RCCL for device tensors under the "nccl" backend), or
+    this library's own RCCL binding when MZ_COMM=rccl."""
+    global _weight_comm
+    if flat.is_cuda and os.environ.get("MZ_COMM") == "rccl":
+        if _weight_comm is None:
+            _weight_comm = WeightComm()
+        _weight_comm.broadcast(flat, src)
+    else:
+        dist.broadcast(flat, src=src)
+
+
 def broadcast_state_dict(sd, src: int = 0, device=None):
     """Broadcast a state_dict from `src` as ONE flat float32 buffer (plus the integer
     entries as a second small one).  Every rank must pass a state_dict with the same
-    keys and shapes (contents are ignored off-source).  Returns the received dict
-    (CPU tensors).  A no-op without an initialised process group."""
+    keys and shapes (contents are ignored off-source).  Returns the received dict: under RCCL its
+    tensors are views into the flat DEVICE buffer (``MuZeroNetwork.load_state_dict`` folds and packs
+    them there; nothing visits the host), under gloo host tensors.  A no-op without an initialised
+    process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sd
     if device is None:
@@ -64,24 +114,20 @@ def broadcast_state_dict(sd, src: int = 0, device=None):
     fkeys = [k for k, v in sd.items() if v.is_floating_point()]
     ikeys = [k for k, v in sd.items() if not v.is_floating_point()]
     flat = torch.cat([sd[k].detach().reshape(-1).float() for k in fkeys]).to(device)
-    dist.broadcast(flat, src=src)
+    _flat_broadcast(flat, src)
     out = OrderedDict()
     off = 0
-    flat = flat.cpu()
-    for k in sd:
-        if k in ikeys:
-            continue
+    for k in fkeys:
         n = sd[k].numel()
-        out[k] = flat[off:off + n].view(sd[k].shape).to(sd[k].dtype).clone()
+        out[k] = flat[off:off + n].view(sd[k].shape).to(sd[k].dtype)      # float32 stays a view
         off += n
     if ikeys:
         iflat = torch.cat([sd[k].detach().reshape(-1).long() for k in ikeys]).to(device)
-        dist.broadcast(iflat, src=src)
-        iflat = iflat.cpu()
+        _flat_broadcast(iflat, src)
         off = 0
         for k in ikeys:
             n = sd[k].numel()
-            out[k] = iflat[off:off + n].view(sd[k].shape).to(sd[k].dtype).clone()
+            out[k] = iflat[off:off + n].view(sd[k].shape).to(sd[k].dtype)
             off += n
     return OrderedDict((k, out[k]) for k in sd)
 

@@ -557,6 +557,11 @@ class Learner:
     def state_dict(self):
         return {k: v.detach().cpu() for k, v in self.network.state_dict().items()}
 
+    def device_state_dict(self):
+        """The parameters where they are (no copy): what ``loop.publish`` broadcasts and the search engine
+        folds and packs on the device."""
+        return {k: v.detach() for k, v in self.network.state_dict().items()}
+
     def save_checkpoint(self, path: str) -> None:
         """The reference's checkpoint dictionary (train.py:481-495)."""
         checkpoint.write(path, self.training_step, self.network, self.optimizer, self.scheduler, self.config)

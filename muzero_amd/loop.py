@@ -217,6 +217,8 @@ def train_steps(learner: Learner, replay: ReplayBuffer, steps: int) -> List[dict
 
 
 def publish(learner: Optional[Learner], network, src: int = 0) -> None:
-    """Rank ``src`` holds the learner; every rank's search engine gets its weights."""
-    sd = learner.state_dict() if learner is not None else network.state_dict()
+    """Rank ``src`` holds the learner; every rank's search engine gets its weights: one flat broadcast
+    (device to device under RCCL), then BatchNorm folding and fragment packing by kernels into the
+    engine's existing weight buffers - the parameters never visit the host."""
+    sd = learner.device_state_dict() if learner is not None else network.state_dict()
     network.load_state_dict(mzdist.broadcast_state_dict(sd, src=src))

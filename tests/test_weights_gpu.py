@@ -111,3 +111,20 @@ def test_transposed_packing_for_the_data_gradient():
               _lib.ptr(out), None, _lib.current_stream())
     want = mfma.pack_weights(w.permute(1, 0, 2, 3).flip(2, 3).contiguous(), 256)
     assert same_bits(out, want)
+
+
+def test_rccl_weight_broadcast_entry_points_single_rank():
+    """mz_comm_* with one rank on the one GPU of this box: the library binds RCCL at run time, creates a
+    communicator and broadcasts a flat buffer in place (a 1-rank broadcast leaves it unchanged).  More ranks
+    need more GPUs; the rank plumbing around it is rehearsed with gloo in the CPU tests."""
+    from muzero_amd import dist as mzdist
+    comm = mzdist.WeightComm()
+    assert comm.world == 1 and comm.rank == 0
+    flat = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    want = flat.clone()
+    comm.broadcast(flat, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want)
+    with pytest.raises(Exception):
+        comm.broadcast(flat, 3)              # root outside the communicator
+    comm.close()
