@@ -27,13 +27,113 @@ import torch.nn.functional as F
 from . import _lib, checkpoint
 
 
+# --------------------------------------------------------------------------- native convolutions
+class _PackedWeights:
+    """Fragment-packed bf16 copies of one convolution's float32 weight (forward form and the
+    transposed, mirrored form of the data gradient), repacked on the device when the parameter has
+    changed (optimizer steps bump its version counter)."""
+
+    def __init__(self):
+        self._slots = {}
+
+    def get(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+        from . import mfma
+        key = (weight.data_ptr(), weight._version)
+        slot = self._slots.get(transpose)
+        # while a HIP graph of the update is being recorded the packing must be part of it (a replay runs no
+        # Python, so the version check cannot happen then): always pack, into the existing buffer
+        if slot is None or slot[0] != key or torch.cuda.is_current_stream_capturing():
+            buf = slot[1] if slot is not None else torch.empty(mfma.packed_elems(256, 256), dtype=torch.bfloat16,
+                                                               device=weight.device)
+            _lib.call("mz_weights_fold_pack", _lib.ptr(weight.detach()), None, None, None, None, None, 0.0, 256, 256, 256,
+                      0, 1 if transpose else 0, 0, _lib.ptr(buf), None, _lib.current_stream())
+            slot = self._slots[transpose] = (key, buf)
+        return slot[1]
+
+
+class _Conv3x3Native(torch.autograd.Function):
+    """conv2d(x, w, b, stride 1, padding 1) for the 12x12, 256->256 layers on this library's kernels:
+    forward and data gradient = mz_conv3x3_bf16 (the latter on the transposed, mirrored weights), weight
+    gradient = mz_conv_wgrad_bf16.  x: bf16 [N, 256, 12, 12] in channels_last memory (= the kernels' NHWC)."""
+
+    @staticmethod
+    def _conv(x_nhwc, wpk, bias):
+        n = x_nhwc.shape[0]
+        out = torch.empty_like(x_nhwc)
+        _lib.call("mz_conv3x3_bf16", _lib.ptr(x_nhwc), None, 0, _lib.ptr(wpk), _lib.ptr(bias), None, _lib.ptr(out), None,
+                  None, None, n, 12, 12, 256, 256, 1, 0, _lib.current_stream())
+        return out
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed):
+        xh = x.permute(0, 2, 3, 1)
+        if not xh.is_contiguous() or x.dtype != torch.bfloat16:
+            raise ValueError("native convolution: bf16 channels_last input expected")
+        ctx.save_for_backward(x, weight)
+        ctx.packed = packed
+        out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float())
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gh, xh = g.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1)
+        n = x.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            zero = torch.zeros(256, dtype=torch.float32, device=x.device)
+            dx = _Conv3x3Native._conv(gh, ctx.packed.get(weight, True), zero).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            need = _lib.lib().mz_conv_wgrad_workspace_bytes(n)
+            ws = _wgrad_workspace(need, x.device)
+            dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
+            _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gh), _lib.ptr(xh), n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(ws),
+                      ws.numel() * 4, _lib.current_stream())
+        if ctx.needs_input_grad[2]:
+            db = g.sum(dim=(0, 2, 3), dtype=torch.float32)
+        return dx, dw, db, None
+
+
+_WGRAD_WS: Dict[tuple, torch.Tensor] = {}
+
+
+def _wgrad_workspace(nbytes: int, device) -> torch.Tensor:
+    """One scratch buffer per device for the weight-gradient partial sums (stream-ordered reuse)."""
+    key = (device.type, device.index)
+    t = _WGRAD_WS.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = _WGRAD_WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+    return t
+
+
+class Conv3x3(nn.Conv2d):
+    """nn.Conv2d(c_in, c_out, 3, stride, 1) whose 12x12, 256->256 instances run on this library's
+    kernels (forward, data gradient, weight gradient) when the learner computes in bf16; every other
+    shape, the CPU and the float32 precision use torch's convolution.  Parameter names are nn.Conv2d's."""
+
+    native = True        # Learner(native_convs=False) clears this on its modules
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__(cin, cout, 3, stride, 1)
+        self._packed = _PackedWeights()
+
+    def forward(self, x):
+        if (self.native and x.is_cuda and torch.is_autocast_enabled() and self.stride == (1, 1)
+                and tuple(self.weight.shape) == (256, 256, 3, 3) and tuple(x.shape[1:]) == (256, 12, 12)):
+            with torch.autocast("cuda", enabled=False):
+                xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                return _Conv3x3Native.apply(xb, self.weight, self.bias, self._packed)
+        return super().forward(x)
+
+
 # --------------------------------------------------------------------------- modules
 class _Res(nn.Module):
     def __init__(self, c):
         super().__init__()
-        self.conv1 = nn.Conv2d(c, c, 3, 1, 1)
+        self.conv1 = Conv3x3(c, c)
         self.bn1 = nn.BatchNorm2d(c)
-        self.conv2 = nn.Conv2d(c, c, 3, 1, 1)
+        self.conv2 = Conv3x3(c, c)
         self.bn2 = nn.BatchNorm2d(c)
 
     def forward(self, x):
@@ -44,7 +144,7 @@ class _Res(nn.Module):
 class _Down(nn.Module):
     def __init__(self, cin, cout, n):
         super().__init__()
-        self.conv = nn.Conv2d(cin, cout, 3, 2, 1)
+        self.conv = Conv3x3(cin, cout, 2)
         self.bn = nn.BatchNorm2d(cout)
         self.blocks = nn.ModuleList([_Res(cout) for _ in range(n)])
 
@@ -67,7 +167,7 @@ def _mlp(cin, hidden, cout):
 class _Representation(nn.Module):
     def __init__(self, cin, width, steps):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, width, 3, 2, 1)
+        self.conv1 = Conv3x3(cin, width, 2)
         self.bn1 = nn.BatchNorm2d(width)
         stages, c = [], width
         for cout, n in steps:
@@ -88,7 +188,7 @@ class _Dynamics(nn.Module):
         super().__init__()
         self.n_actions = n_actions
         self.conv_action = nn.Conv2d(n_actions, width, 1)
-        self.conv_state = nn.Conv2d(width, width, 3, 1, 1)
+        self.conv_state = Conv3x3(width, width)
         self.bn = nn.BatchNorm2d(width)
         self.resblocks = nn.ModuleList([_Res(width) for _ in range(n_blocks)])
         self.reward_head = _mlp(width, fc_reward, 2 * support + 1)
@@ -529,10 +629,13 @@ def unroll_actions(action_lists, K: int) -> np.ndarray:
 
 class Learner:
     def __init__(self, config, device="cuda", state_dict=None, loss_impl=None,
-                 precision: str = "fp32", autotune: bool = True, data_parallel: bool = False):
+                 precision: str = "fp32", autotune: bool = True, data_parallel: bool = False,
+                 native_convs: bool = True):
         """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
         convolutions and linear layers under bfloat16 autocast with float32 master weights,
-        BatchNorm statistics and losses.  autotune: see below."""
+        BatchNorm statistics and losses - and, with native_convs, the 12x12 256->256 convolutions
+        (forward, data gradient, weight gradient) on this library's MFMA kernels instead of MIOpen.
+        autotune: see below."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         if autotune and torch.device(device).type == "cuda":
@@ -548,6 +651,10 @@ class Learner:
         self.network = TrainableNetwork(config).to(self.device)      # stays in training mode (train.py:155)
         if state_dict is not None:
             self.network.load_state_dict(state_dict)
+        self.native_convs = bool(native_convs and precision == "bf16" and self.device.type == "cuda")
+        for m in self.network.modules():
+            if isinstance(m, Conv3x3):
+                m.native = self.native_convs
         self.optimizer = torch.optim.SGD(self.network.parameters(), lr=config.lr_init, momentum=config.momentum,
                                          weight_decay=config.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=config.lr_decay_steps,
@@ -641,6 +748,60 @@ class Learner:
         """``update_weights`` for a batch already in tensor form (see ``losses_from_tensors``)."""
         return self._step(*self.losses_from_tensors(observations, actions, target_values, target_rewards,
                                                     target_policies, weights))
+
+    # ---- the whole update as one HIP graph
+    def update_graphed(self, observations, actions, target_values, target_rewards, target_policies, weights):
+        """``update_from_tensors`` replayed from a HIP graph: losses, backward pass, gradient clipping and the
+        SGD step of one batch shape are recorded once (after three eager warm-up updates on that shape)
+        and then replayed - an eager update is ~2000 kernel launches and bound by the host that issues them.
+        The graph is recorded again when the batch shape or the learning rate changes.  Returns the same
+        dictionary; the metrics are read back after the replay."""
+        if self.data_parallel:
+            raise NotImplementedError("the graphed update does not include the gradient all-reduce")
+        dev = self.device
+        ins = [torch.as_tensor(observations).to(dev, torch.float32), torch.as_tensor(actions).to(dev, torch.long),
+               torch.as_tensor(target_values).to(dev, torch.float32), torch.as_tensor(target_rewards).to(dev, torch.float32),
+               torch.as_tensor(target_policies).to(dev, torch.float32), torch.as_tensor(weights).to(dev, torch.float32)]
+        key = (tuple(tuple(t.shape) for t in ins), tuple(g["lr"] for g in self.optimizer.param_groups))
+        st = getattr(self, "_graph_state", None)
+        if st is None or st["key"] != key:
+            static = [t.clone() for t in ins]
+
+            def body():
+                v, r, p, per = self.losses_from_tensors(*static)
+                loss = per.mean()
+                self.optimizer.zero_grad(set_to_none=True)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.config.max_grad_norm)
+                self.optimizer.step()
+                return torch.stack([v.detach().reshape(()), r.detach().reshape(()), p.detach().reshape(()), loss.detach()]), per.detach()
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):                         # allocations, solver choices, momentum buffers
+                    body()
+                    self.scheduler.step()
+                    self.training_step += 1
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                outs = body()
+            st = self._graph_state = {"key": key, "graph": graph, "static": static, "outs": outs, "warmup_updates": 3}
+            return self._graph_replay(st, ins)             # (the recording itself executed nothing)
+        return self._graph_replay(st, ins)
+
+    def _graph_replay(self, st, ins):
+        for dst, src in zip(st["static"], ins):
+            dst.copy_(src, non_blocking=True)
+        st["graph"].replay()
+        self.scheduler.step()
+        self.training_step += 1
+        m, per = st["outs"]
+        m = m.cpu().numpy()
+        return {"value_loss": float(m[0]), "reward_loss": float(m[1]), "policy_loss": float(m[2]),
+                "total_loss": float(m[3]), "priorities": per.cpu().numpy()}
 
     def _step(self, v, r, p, per):
         loss = per.mean()

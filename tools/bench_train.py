@@ -104,11 +104,17 @@ def main():
     tp = rng.dirichlet(np.ones(A), (B, K + 1))
     w = np.ones(B)
     fwd = 5_181_014_016 + K * 850_364_416      # forward FLOPs per position; backward ~2x forward
-    for precision in ("fp32", "bf16"):
-        lrn = Learner(cfg, device=dev, state_dict=init_state_dict(cfg, seed=0), precision=precision)
+    for tag, precision, native, graphed in (("fp32", "fp32", False, False), ("bf16_torch_convs", "bf16", False, False),
+                                            ("bf16_native_convs", "bf16", True, False),
+                                            ("bf16_torch_convs_graphed", "bf16", False, True),
+                                            ("bf16_native_convs_graphed", "bf16", True, True)):
+        lrn = Learner(cfg, device=dev, state_dict=init_state_dict(cfg, seed=0), precision=precision,
+                      native_convs=native, autotune=args.autotune)
+        if graphed:
+            lrn.update_from_tensors = lrn.update_graphed
         if args.channels_last:
             lrn.network.to(memory_format=torch.channels_last)
-        for _ in range(2):
+        for _ in range(4):
             lrn.update_from_tensors(obs, acts, tv, tr, tp, w)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -116,7 +122,7 @@ def main():
             m = lrn.update_from_tensors(obs, acts, tv, tr, tp, w)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
-        out["update_weights_" + precision] = {"batch": B, "unroll": K, "ms_per_step": dt * 1e3,
+        out["update_weights_" + tag] = {"batch": B, "unroll": K, "ms_per_step": dt * 1e3,
                                               "positions_per_s": B / dt, "model_TFLOP/s": 3 * fwd * B / dt / 1e12,
                                               "loss": m["total_loss"]}
         del lrn
