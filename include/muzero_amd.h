@@ -303,7 +303,8 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 
 /* Stacked, normalised observation from the ring: out[b][pixel][age*3 + rgb] =
  * frame(age)[pixel][rgb] / 255 with age 0 = oldest = slot (newest_slot+1) % D
- * (train.py:62-63 then :534-540). out is NHWC, float32 or bf16 (out_is_bf16). */
+ * (train.py:62-63 then :534-540). out is NHWC: float32 (out_is_bf16 = 0), bf16 (1), or the bf16x3 precision's
+ * (hi, lo) bf16 pairs of the float32 value, [B][2][HW][3*D] (2; needs 3*D % 8 == 0 and HW % 64 == 0). */
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* _
 // Fast path of the same conversion for 3*D a multiple of 8 and HW a multiple of 64: every
 // global access is 16 bytes per lane (the byte-at-a-time version above is bound by the
 // number of memory instructions, not by bytes).
-template <typename OutT>
+// SPLIT: OutT is bf16 and the output is the (hi, lo) pair layout [B][2][HW][C] of the bf16x3 precision:
+// hi = bf16(v), lo = bf16(v - hi).
+template <typename OutT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned char* __restrict__ ring,
                                                              OutT* __restrict__ out, int D, int HW, int newest) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,7 +88,19 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
       v[j] = (float)st[f * row + px * 3 + r] / 255.0f;
     }
     const long o = ((long)b * HW + p0 + px) * C + c0;
-    if constexpr (sizeof(OutT) == 2) {
+    if constexpr (SPLIT) {
+      unsigned short hi[8], lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        hi[j] = f32_to_bf16_rne(v[j]);
+        lo[j] = f32_to_bf16_rne(v[j] - __uint_as_float((unsigned)hi[j] << 16));
+      }
+      const long oh = ((long)b * 2 * HW + p0 + px) * C + c0, ol = oh + (long)HW * C;
+      *reinterpret_cast<uint4*>(out + oh) = make_uint4(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16),
+                                                        hi[4] | ((unsigned)hi[5] << 16), hi[6] | ((unsigned)hi[7] << 16));
+      *reinterpret_cast<uint4*>(out + ol) = make_uint4(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
+                                                        lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
+    } else if constexpr (sizeof(OutT) == 2) {
       uint4 pk;
       pk.x = f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
       pk.y = f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
@@ -174,6 +188,13 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
   const size_t lds = (size_t)D * kPix * 3;
   MZ_REQUIRE(lds <= 64 * 1024, "mz_ring_to_obs: ring depth %d too large", D);
   const dim3 grid((HW + kPix - 1) / kPix, B);
+  MZ_REQUIRE(out_is_bf16 >= 0 && out_is_bf16 <= 2, "mz_ring_to_obs: output format must be 0 (float32), 1 (bf16) or 2 (pairs)");
+  if (out_is_bf16 == 2) {
+    MZ_REQUIRE((3 * D) % 8 == 0 && HW % kPix == 0, "mz_ring_to_obs: the pair format needs 3*D %% 8 == 0 and HW %% 64 == 0");
+    hipLaunchKernelGGL((ring_to_obs_vec_kernel<unsigned short, true>), grid, dim3(256), lds, mz::as_stream(stream), ring,
+                       static_cast<unsigned short*>(out), D, HW, newest_slot);
+    return mz::check_launch("mz_ring_to_obs");
+  }
   if ((3 * D) % 8 == 0 && HW % kPix == 0) {
     if (out_is_bf16)
       hipLaunchKernelGGL(ring_to_obs_vec_kernel<unsigned short>, grid, dim3(256), lds, mz::as_stream(stream), ring,

@@ -450,8 +450,12 @@ class MuZeroNetwork:
                 obs_nhwc = untile(obs_nhwc).contiguous()
         else:
             B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2]
+        pairs_in = self.split and rotation is None and obs_nhwc.dim() == 5     # already (hi, lo) pairs
+        if pairs_in:
+            H, W = obs_nhwc.shape[2], obs_nhwc.shape[3]
+            _lib.expect(obs_nhwc, "observation", torch.bfloat16, (B, 2, H, W, self.cin))
         hh, hw = self.hidden_hw(H, W)
-        if not rot_kernel:
+        if not rot_kernel and not pairs_in:
             _lib.expect(obs_nhwc, "observation", self.obs_dtype, (B, H, W, self.cin))
         _lib.expect(hidden_out, "hidden_out", self.act_dtype, self.act_shape(B, hh, hw, self.W))
         _lib.expect(mean_out, "mean_out", torch.float32, (B, self.W))
@@ -459,7 +463,7 @@ class MuZeroNetwork:
         if self.split:
             if rotation is not None:
                 raise NotImplementedError("bf16x3 takes the observation in the reference's channel order")
-            x = self._split(obs_nhwc)
+            x = obs_nhwc if pairs_in else self._split(obs_nhwc)
         plan = self.rep_plan
         # the trailing residual blocks at the hidden resolution run as one fused chain
         n_tail = 0

@@ -82,14 +82,19 @@ class FrameRing:
         newest = self.newest if newest is None else newest
         return rotation_permutation(self.depth, newest)
 
-    def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None) -> torch.Tensor:
-        """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255."""
-        if dtype not in (torch.bfloat16, torch.float32):
+    def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None, pairs: bool = False) -> torch.Tensor:
+        """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255.  pairs: the float32
+        value as (hi, lo) bf16 pairs [B, 2, H, W, 3*depth] (the bf16x3 precision's input)."""
+        if pairs:
+            dtype, shape, mode = torch.bfloat16, (self.B, 2, self.H, self.W, 3 * self.depth), 2
+        elif dtype in (torch.bfloat16, torch.float32):
+            shape, mode = (self.B, self.H, self.W, 3 * self.depth), 1 if dtype == torch.bfloat16 else 0
+        else:
             raise ValueError("observation dtype must be bfloat16 or float32")
         if out is None:
-            out = torch.empty(self.B, self.H, self.W, 3 * self.depth, dtype=dtype, device=self.device)
-        _lib.expect(out, "out", dtype, (self.B, self.H, self.W, 3 * self.depth))
-        _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
+            out = torch.empty(*shape, dtype=dtype, device=self.device)
+        _lib.expect(out, "out", dtype, shape)
+        _lib.call("mz_ring_to_obs", _lib.ptr(self.ring), _lib.ptr(out), mode,
                   self.B, self.depth, self.H * self.W, self.newest, _lib.current_stream())
         return out
 

@@ -56,7 +56,8 @@ class SelfPlayWorker:
             self.ring.enable_rotating(network.obs_dtype)   # a move then rewrites 3 of the 96 channels per pixel
         self.mcts = BatchedMCTS(config, network, batch_size, num_simulations, wave, obs_hw)
         self._obs = None
-        self._obs_shape = (batch_size, obs_hw[0], obs_hw[1], 3 * frame_stack)
+        self.pairs = bool(getattr(network, "split", False))    # bf16x3 takes the observation as (hi, lo) pairs
+        self._obs_shape = ((batch_size, 2) if self.pairs else (batch_size,)) + (obs_hw[0], obs_hw[1], 3 * frame_stack)
         self.rng = np.random.default_rng(seed)
         self.noise = torch.empty(batch_size, self.A, dtype=torch.float64, device=network.device)
         self.u = torch.empty(batch_size, dtype=torch.float64, device=network.device)
@@ -67,7 +68,8 @@ class SelfPlayWorker:
         """Buffer for the stacked observation in the reference's channel order (allocated on first
         use: the rotating path never needs it)."""
         if self._obs is None:
-            self._obs = torch.empty(*self._obs_shape, dtype=self.net.obs_dtype, device=self.net.device)
+            self._obs = torch.empty(*self._obs_shape, dtype=torch.bfloat16 if self.pairs else self.net.obs_dtype,
+                                    device=self.net.device)
         return self._obs
 
     def reset(self, frames: torch.Tensor) -> None:
@@ -92,7 +94,7 @@ class SelfPlayWorker:
         if self.rotating:
             obs, newest = self.ring.rotating_observation()
         else:
-            obs, newest = self.ring.observation(self.net.obs_dtype, out=self.obs), None
+            obs, newest = self.ring.observation(self.net.obs_dtype, out=self.obs, pairs=self.pairs), None
         res: SearchResult = self.mcts.run(obs, self.noise if add_noise else None, rotation=newest)
         actions = select_actions(res.visit_counts, temperature, self.u if temperature != 0 else None)
         return actions, res

@@ -290,3 +290,33 @@ def test_graph_replay_of_the_rotating_path_and_stale_graph_guard():
     eager = worker.mcts.run(obs, worker.noise, rotation=worker.ring.newest)
     v = eager.visit_counts.cpu().numpy().copy()
     assert np.array_equal(fresh().visit_counts.cpu().numpy(), v)
+
+
+def test_pair_observation_for_the_float32_accurate_precision():
+    """FrameRing.observation(pairs=True) = the float32 observation split into (hi, lo) bf16 pairs, bit for bit;
+    a self-play step in the bf16x3 precision consumes it and gives the stacked-float32-observation result."""
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.search import BatchedMCTS
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg = MuZeroConfig()
+    cfg.action_space_size, cfg.num_simulations = 6, 8
+    net = MuZeroNetwork(cfg, precision="bf16x3", state_dict=init_state_dict(cfg, seed=2, randomize_bn=True))
+    B = 5
+    worker = SelfPlayWorker(cfg, net, B, 8)
+    assert worker.pairs and not worker.rotating
+    env = SyntheticEnv(B, device="cuda", pool=8)
+    worker.reset(env.reset())
+    for _ in range(35):
+        worker.ring.push(env.step())
+    f32 = worker.ring.observation(torch.float32)
+    pairs = worker.ring.observation(pairs=True)
+    assert pairs.shape == (B, 2, 96, 96, 96) and pairs.dtype == torch.bfloat16
+    want = net._split(f32)
+    assert torch.equal(pairs.view(torch.int16), want.view(torch.int16))
+    worker.draw_randomness()
+    actions, res = worker.step(None, temperature=0, add_noise=True)
+    v = res.visit_counts.cpu().numpy().copy()
+    other = BatchedMCTS(cfg, net, B, 8).run(f32, worker.noise)
+    assert np.array_equal(other.visit_counts.cpu().numpy(), v)
+    assert np.array_equal(other.root_values.cpu().numpy(), res.root_values.cpu().numpy())
