@@ -18,7 +18,7 @@ import torch  # noqa: E402
 
 from muzero_amd import dist as mzdist, loop  # noqa: E402
 from muzero_amd.config import MuZeroConfig  # noqa: E402
-from muzero_amd.learner import Learner, ReplayBuffer  # noqa: E402
+from muzero_amd.learner import EpisodeStore, Learner, ReplayBuffer  # noqa: E402
 from muzero_amd.network import MuZeroNetwork, init_state_dict  # noqa: E402
 from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv  # noqa: E402
 
@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--actions", type=int, default=4)
     ap.add_argument("--data-parallel", action="store_true", help="every rank trains; gradients all-reduced")
+    ap.add_argument("--learner-precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--graphed", action="store_true", help="replay each update from a HIP graph")
     args = ap.parse_args()
 
     rank, world, local = mzdist.init_from_env()
@@ -44,8 +46,9 @@ def main():
     sd = mzdist.broadcast_state_dict(init_state_dict(cfg, seed=rank), src=0)
     net = MuZeroNetwork(cfg, precision="bf16", device=dev, state_dict=sd)
     trains = rank == 0 or args.data_parallel
-    learner = Learner(cfg, device=dev, state_dict=sd, data_parallel=args.data_parallel) if trains else None
-    replay = ReplayBuffer(cfg)
+    learner = Learner(cfg, device=dev, state_dict=sd, data_parallel=args.data_parallel,
+                      precision=args.learner_precision) if trains else None
+    replay = ReplayBuffer(cfg, EpisodeStore(args.actions, cfg.discount, dev))
     worker = SelfPlayWorker(cfg, net, args.games, args.sims, seed=100 + rank)
     env = SyntheticEnv(args.games, seed=7 + rank, device=dev)
     rng = np.random.default_rng(rank)
@@ -61,13 +64,16 @@ def main():
         t1 = time.time()
         if trains:
             loop.save_games(replay, games, cfg.td_steps)
-            metrics = loop.train_steps(learner, replay, args.train_steps)
+            metrics = loop.train_steps(learner, replay, args.train_steps, graphed=args.graphed)
+        torch.cuda.synchronize()
+        t2 = time.time()
         loop.publish(learner, net)   # rank 0's weights (and BatchNorm statistics) reach every search engine
         torch.cuda.synchronize()
+        t3 = time.time()
         if rank == 0:
             m = metrics[-1]
             print(f"iter {it}: self-play {args.games * args.moves * args.sims / (t1 - t0):.0f} sims/s/GPU, "
-                  f"{args.train_steps} updates in {time.time() - t1:.2f}s, loss {m['total_loss']:.4f} "
+                  f"{args.train_steps} updates in {t2 - t1:.2f}s, publish {1e3 * (t3 - t2):.1f} ms, loss {m['total_loss']:.4f} "
                   f"(value {m['value_loss']:.3f} reward {m['reward_loss']:.3f} policy {m['policy_loss']:.3f})",
                   flush=True)
     if world > 1:

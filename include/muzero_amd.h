@@ -325,6 +325,15 @@ int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int
 int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,
                            mz_stream_t stream);
 
+/* The observations of a training batch from device-resident episode frames (Game.get_observation + the
+ * prepare_observation of compute_losses, train.py:128-129, :343, :529-540; model.py:603): frames uint8
+ * [positions][HW][3] holds the single new frame of every stored position, episodes back to back; game g's first
+ * frame is frames[frame_off[g]] (int64 [n_games + 1]).  Sample b = position q_pos[b] of game q_game[b]: the D
+ * frames ending there, the episode's first frame repeated in front (train.py:49-50), oldest first.  out: float32
+ * NCHW [n][3*D][HW], x / 255.  The caller guarantees 0 <= q_pos[b] < length of game q_game[b]. */
+int mz_gather_stacked_obs(const uint8_t* frames, const int64_t* frame_off, const int32_t* q_game, const int32_t* q_pos,
+                          int32_t n, int32_t D, int32_t HW, float* out_nchw, mz_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Weight hand-over on the device: from the float32 parameters of a state_dict (e.g. views into
  * the flat buffer a weight broadcast filled) to what the kernels read.  The reference shares one

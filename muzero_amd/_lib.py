@@ -69,6 +69,7 @@ _SIGNATURES = {
     "mz_conv3x3_bf16_rot_sel": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mz_obs_slot_write": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                     _P]),
+    "mz_gather_stacked_obs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_packed_conv_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "mz_weights_fold_pack": (C.c_int, [_P] * 6 + [C.c_double] + [C.c_int32] * 6 + [_P, _P, _P]),

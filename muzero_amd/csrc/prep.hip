@@ -166,6 +166,25 @@ __global__ void prepare_observation_kernel(const unsigned char* __restrict__ in,
   }
 }
 
+
+// Stacked, prepared observations of n replay positions from device-resident episode frames: sample b is
+// position q_pos[b] of game q_game[b]; its stack holds the D frames ending at that position, the first frame
+// of the episode repeated in front (CustomFrameStack's reset rule, train.py:49-50), oldest first, as
+// prepare_observation leaves it: float32 NCHW, x / 255.  One workgroup = 64 pixels of one frame of one sample.
+__global__ __launch_bounds__(192) void gather_stacked_obs_kernel(const unsigned char* __restrict__ frames,
+                                                                const long* __restrict__ frame_off,
+                                                                const int* __restrict__ q_game,
+                                                                const int* __restrict__ q_pos, int D, int HW,
+                                                                float* __restrict__ out) {
+  const int b = blockIdx.z, k = blockIdx.y, p0 = blockIdx.x * 64;
+  const int c = threadIdx.x / 64, px = threadIdx.x % 64;
+  if (p0 + px >= HW) return;
+  int pos = q_pos[b] - D + 1 + k;
+  pos = pos < 0 ? 0 : pos;
+  const unsigned char* f = frames + (frame_off[q_game[b]] + pos) * (long)HW * 3;
+  out[((long)b * 3 * D + k * 3 + c) * HW + p0 + px] = (float)f[(p0 + px) * 3 + c] / 255.0f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -226,6 +245,15 @@ int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int
     hipLaunchKernelGGL(obs_slot_write_kernel<float>, grid, dim3(256), 0, mz::as_stream(stream), frames,
                        static_cast<float*>(obs), D, HW, slot, fill_all, fill_mask);
   return mz::check_launch("mz_obs_slot_write");
+}
+
+int mz_gather_stacked_obs(const uint8_t* frames, const int64_t* frame_off, const int32_t* q_game, const int32_t* q_pos,
+                          int32_t n, int32_t D, int32_t HW, float* out_nchw, mz_stream_t stream) {
+  MZ_REQUIRE(frames && frame_off && q_game && q_pos && out_nchw && n > 0 && D > 0 && HW > 0 && n <= 65535 && D <= 65535,
+             "mz_gather_stacked_obs: bad arguments");
+  hipLaunchKernelGGL(gather_stacked_obs_kernel, dim3((HW + 63) / 64, D, n), dim3(192), 0, mz::as_stream(stream), frames,
+                     reinterpret_cast<const long*>(frame_off), q_game, q_pos, D, HW, out_nchw);
+  return mz::check_launch("mz_gather_stacked_obs");
 }
 
 int mz_prepare_observation(const uint8_t* obs_nhwc, float* out_nchw, int32_t B, int32_t C, int32_t HW,

@@ -192,9 +192,10 @@ def save_games(replay: ReplayBuffer, games: List[GameHistory], td_steps: int) ->
         replay.save_game(g, full)
 
 
-def train_steps(learner: Learner, replay: ReplayBuffer, steps: int) -> List[dict]:
+def train_steps(learner: Learner, replay: ReplayBuffer, steps: int, graphed: bool = False) -> List[dict]:
     """train.py:295-319.  With a device episode store behind the replay buffer the targets of
-    the whole batch come from one kernel launch; otherwise from ``make_target`` per position."""
+    the whole batch come from one kernel launch; otherwise from ``make_target`` per position.
+    graphed: replay each update from a HIP graph (``Learner.update_graphed``; needs the episode store)."""
     cfg = learner.config
     K = cfg.num_unroll_steps
     out = []
@@ -203,10 +204,13 @@ def train_steps(learner: Learner, replay: ReplayBuffer, steps: int) -> List[dict
         games = [replay.buffer[int(g)] for g in gi]
         if replay.store is not None:
             tv, tr, tp = replay.store.targets(gi, pos, K, cfg.td_steps)
-            obs = torch.from_numpy(np.stack([g.get_observation(int(p)) for g, p in zip(games, pos)]))
-            obs = obs.to(learner.device).permute(0, 3, 1, 2).float() / 255.0
+            if replay.store.frames is not None:      # frames live on the device: one gather kernel
+                obs = replay.store.observations(gi, pos)
+            else:
+                obs = torch.from_numpy(np.stack([g.get_observation(int(p)) for g, p in zip(games, pos)]))
+                obs = obs.to(learner.device).permute(0, 3, 1, 2).float() / 255.0
             acts = unroll_actions([g.actions[int(p):int(p) + K] for g, p in zip(games, pos)], K)    # model.py:604
-            m = learner.update_from_tensors(obs, acts, tv, tr, tp, weights)
+            m = (learner.update_graphed if graphed else learner.update_from_tensors)(obs, acts, tv, tr, tp, weights)
         else:
             batch = [(g.get_observation(int(p)), g.actions[int(p):int(p) + K], g.make_target(int(p), K, cfg.td_steps))
                      for g, p in zip(games, pos)]                                                  # model.py:602-606

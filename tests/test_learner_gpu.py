@@ -329,3 +329,36 @@ def test_continuous_selfplay_on_the_device():
         # the frames of the final environment step are not in the stack yet (the next move pushes them)
         assert len(set(episodes.tolist())) == 1 and episodes[0] == pool.envs[i].ep - int(pool.restarted[i])
     pool.close()
+
+
+def test_device_resident_frames_give_the_reference_observations():
+    """EpisodeStore.observations (one gather kernel over device-resident frames) against Game.get_observation
+    restated on the host (the stack of the 32 frames before a position, first frame repeated) followed by the
+    oracle's prepare_observation: bit for bit, including positions near the start of an episode, the window's
+    eviction and the store's compaction offsets."""
+    from muzero_amd.learner import EpisodeStore, GameHistory
+    from oracle import prep as oprep
+    rng = np.random.default_rng(4)
+    A, D = 4, 32
+    store = EpisodeStore(A, 0.997)
+    games = []
+    for T in (1, 5, 40, 33):
+        g = GameHistory(A, 0.997, frame_stack=D)
+        for t in range(T):
+            g.store_transition(None if t == 0 else int(rng.integers(0, A)), rng.integers(0, 256, (96, 96, 3), dtype=np.uint8),
+                               float(rng.normal()))
+            g.values.append(float(rng.normal()))
+            g.policies.append(rng.dirichlet(np.ones(A)))
+        games.append(g)
+        store.add_game(g)
+    q = [(0, 0), (1, 0), (1, 4), (2, 0), (2, 30), (2, 31), (2, 39), (3, 32), (3, 7)]
+    got = store.observations([a for a, _ in q], [b for _, b in q]).cpu().numpy()
+    for i, (gi, p) in enumerate(q):
+        want = oprep.prepare(games[gi].get_observation(p))               # HWC uint8 -> CHW float32 / 255
+        assert np.array_equal(got[i], want), (gi, p)
+    store.pop_front()                                                     # game 0 leaves the window
+    got = store.observations([0, 2], [3, 10]).cpu().numpy()
+    assert np.array_equal(got[0], oprep.prepare(games[1].get_observation(3)))
+    assert np.array_equal(got[1], oprep.prepare(games[3].get_observation(10)))
+    with pytest.raises(IndexError):
+        store.observations([0], [5])                                      # game 1 has 5 positions: 0..4
