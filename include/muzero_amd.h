@@ -402,14 +402,16 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
 
 /* Weight gradient of a 3x3 convolution (padding 1, stride 1) for the unrolled training step (compute_losses'
  * backward pass, train.py:303-308): dw float [Cout][Cin][3][3] = sum over images and pixels of
- * grad_out[n][y][x][co] * x[n][y+ky-1][x+kx-1][ci]; grad_out and x bf16 NHWC, float32 accumulation.  A kernel
+ * grad_out[n][y][x][co] * x[n][y+ky-1][x+kx-1][ci]; grad_out and x bf16 NHWC, float32 accumulation; dbias
+ * (optional, float [Cout]) = sum over images and pixels of grad_out, from the same pass.  A kernel
  * exists for the 12x12, 256->256 shape (23 of the 31 convolutions); other shapes return MZ_E_ARG.  workspace:
  * caller-owned device memory of at least mz_conv_wgrad_workspace_bytes(B) bytes (partial sums of the image
  * shares).  The matching data gradient is mz_conv3x3_bf16 applied to grad_out with weights packed by
  * mz_weights_fold_pack(transpose = 1) and a zero bias. */
 int64_t mz_conv_wgrad_workspace_bytes(int32_t B);
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
-                       int32_t Cout, float* dw, void* workspace, int64_t workspace_bytes, mz_stream_t stream);
+                       int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                       mz_stream_t stream);
 
 /* ReplayBuffer.sample_batch's draw (model.py:580-588) on device-resident priorities: double prio [n], one per
  * stored position, oldest game first.  u: double [batch], the [0,1) draws np.random.choice would consume.

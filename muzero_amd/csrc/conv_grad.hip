@@ -46,7 +46,8 @@ __device__ __forceinline__ s16x4 read_tr(int lds_addr) {
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __restrict__ gout,
                                                            const __bf16* __restrict__ x, int n_images,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial,
+                                                           float* __restrict__ db_partial) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* gs = lds;
   char* xs = lds + kGBytes;
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_db = db_partial != nullptr && (tile & 1) == 0;  // one of the two input-channel tiles does it
+  float dbacc = 0.f;
 
   const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   // lane 4q + p4 of a 16-lane group supplies row q, columns 4 p4 .. 4 p4 + 3 of the block it reads
@@ -116,6 +119,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
     if (x4_ok) *reinterpret_cast<uint4*>(xs + xd4) = x4;
     __syncthreads();
     if (n + shares < n_images) MZ_LOAD_IMAGE(n + shares);  // travels while this image is multiplied
+    if (want_db) {  // bias gradient = column sums of gout: 8 row groups x 64 channels of the staged slice
+#pragma unroll
+      for (int r = tid >> 6; r < kPix; r += 8)
+        dbacc += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(gs + r * kGRow + (tid & 63) * 2) << 16);
+    }
 #pragma unroll 1
     for (int ks = 0; ks < kKSteps; ++ks) {
       // the two pixel rows this lane addresses in this k-step, and where their tap-(0,0) neighbours sit in xs
@@ -146,6 +154,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
     __syncthreads();  // everyone has read this image
   }
 
+  if (want_db) {  // (the loop's last barrier has passed: the staging area is free)
+    float* red = reinterpret_cast<float*>(lds);
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) s += red[g * 64 + tid];
+      db_partial[share * kCh + co0 + tid] = s;
+    }
+  }
   // partial[share][tap][co][ci]: a lane holds rows (co) 4 kq .. 4 kq + 3 of column (ci) lane % 16
   float* dst = partial + (long)share * 9 * kCh * kCh;
   const int ci = ci0 + wave * 16 + (lane & 15);
@@ -160,8 +179,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
 
 // dW[co][ci][tap] = sum over shares of partial[share][tap][co][ci]; one thread per (co, ci)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int shares,
-                                                          float* __restrict__ dw) {
+                                                          float* __restrict__ dw, const float* __restrict__ db_partial,
+                                                          float* __restrict__ db) {
   const int i = blockIdx.x * 256 + threadIdx.x;  // co * 256 + ci
+  if (db && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int g = 0; g < shares; ++g) s += db_partial[g * kCh + threadIdx.x];
+    db[threadIdx.x] = s;
+  }
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
@@ -186,11 +211,12 @@ int32_t mz_conv_wgrad_shares(int32_t B) {
 }
 
 int64_t mz_conv_wgrad_workspace_bytes(int32_t B) {
-  return (int64_t)mz_conv_wgrad_shares(B) * 9 * kCh * kCh * 4;
+  return (int64_t)mz_conv_wgrad_shares(B) * (9 * kCh * kCh + kCh) * 4;  // dW partials, then bias partials
 }
 
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
-                       int32_t Cout, float* dw, void* workspace, int64_t workspace_bytes, mz_stream_t stream) {
+                       int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                       mz_stream_t stream) {
   MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16: null tensor or empty batch");
   MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
              "mz_conv_wgrad_bf16: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin, Cout);
@@ -202,10 +228,11 @@ int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H
     return rc;
   const int shares = mz_conv_wgrad_shares(B);
   hipStream_t s = mz::as_stream(stream);
+  float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * kCh * kCh : nullptr;
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, static_cast<const __bf16*>(grad_out),
-                     static_cast<const __bf16*>(x), B, static_cast<float*>(workspace));
+                     static_cast<const __bf16*>(x), B, static_cast<float*>(workspace), dbp);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kCh * kCh / 256), dim3(256), 0, s, static_cast<const float*>(workspace),
-                     shares, dw);
+                     shares, dw, dbp, dbias);
   return mz::check_launch("mz_conv_wgrad_bf16");
 }
 

@@ -66,21 +66,26 @@ constexpr int kRowB = kCh * 2 + 16;
 constexpr int kOutBytes = kPix * kRowB;           // 76 032
 constexpr int kLdsTotal = kLdsBytes + kOutBytes;  // 157 952 of the CU's 163 840
 
-template <int NW, int PF>
+// SPLIT workgroups share one image, each computing 256 / SPLIT of the output channels (its own staging of the
+// image, the same accumulation order per output: results do not depend on SPLIT).  SPLIT = 2 serves batches
+// of at most half as many images as there are CUs - a training batch of 128.
+template <int NW, int PF, int SPLIT = 1>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldsB = lds + kLdsBytes;
-  constexpr int WN = 16 / NW;  // 16-channel output tiles per wavefront
+  constexpr int WN = 16 / (NW * SPLIT);  // 16-channel output tiles per wavefront
+  static_assert(WN >= 1, "at least one channel tile per wavefront");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
+  const int b = blockIdx.x / SPLIT;
+  const int tile0 = ((blockIdx.x % SPLIT) * NW + wave) * WN;  // this wavefront's first 16-channel tile
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
   const __bf16* src = a.in + img * (long)(kPix * kCh);
   const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
   const int r16 = lane & 15, kq = lane >> 4;
 
   // weight fragments: [k-step][n-tile][lane][8]; prefetched PF k-steps ahead
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) + (long)wave * WN * 64 + lane;
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) + (long)tile0 * 64 + lane;
   constexpr int WSTEP = 16 * 64;
   bf16x8 w0[WN], w1[WN];
 #pragma unroll
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   if (a.residual) {  // the accumulation starts from the residual (as in the chain kernels)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
-      const int cbase = (wave * WN + nt) * 16 + kq * 4;
+      const int cbase = (tile0 + nt) * 16 + kq * 4;
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) {
         const bf16x4 r = *reinterpret_cast<const bf16x4*>(ldsB + (mt * 16 + r16) * kRowB + cbase * 2);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   // apply ReLU, round to bf16 and park the result in LDS region B
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
-    const int cbase = (wave * WN + nt) * 16 + kq * 4;
+    const int cbase = (tile0 + nt) * 16 + kq * 4;
     const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -212,10 +217,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   __syncthreads();
   // epilogue, part 2: the finished image leaves LDS as whole 512-byte rows, 16 bytes per lane
   __bf16* dst = a.out + (long)b * (kPix * kCh);
+  constexpr int UPP = 32 / SPLIT;  // 16-byte units per pixel that this workgroup produced
 #pragma unroll
-  for (int j = 0; j < kPix * 32 / (64 * NW); ++j) {
-    const int u = tid + 64 * NW * j, pix = u >> 5, c16 = u & 31;
-    *reinterpret_cast<bf16x8*>(dst + u * 8) = *reinterpret_cast<const bf16x8*>(ldsB + pix * kRowB + c16 * 16);
+  for (int j = 0; j < (kPix * UPP + 64 * NW - 1) / (64 * NW); ++j) {
+    const int u = tid + 64 * NW * j, pix = u / UPP, c16 = (blockIdx.x % SPLIT) * UPP + u % UPP;
+    if (u < kPix * UPP)
+      *reinterpret_cast<bf16x8*>(dst + (pix * 32 + c16) * 8) = *reinterpret_cast<const bf16x8*>(ldsB + pix * kRowB + c16 * 16);
   }
 }
 
@@ -801,12 +808,12 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
   if (a.B < 0) a.mean_out[tid] = __int_as_float(touched);  // never true: B > 0 is checked by the host
 }
 
-template <int NW, int PF>
+template <int NW, int PF, int SPLIT>
 int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv_trunk_kernel<NW, PF>;
+  auto kern = conv_trunk_kernel<NW, PF, SPLIT>;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsTotal, configured, "conv_trunk")) return rc;
-  hipLaunchKernelGGL(kern, dim3(B), dim3(64 * NW), kLdsTotal, stream, a);
+  hipLaunchKernelGGL(kern, dim3(B * SPLIT), dim3(64 * NW), kLdsTotal, stream, a);
   return mz::check_launch("mz_conv3x3_bf16 (trunk)");
 }
 
@@ -825,7 +832,9 @@ int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
                     float* mean_out, int32_t B, int32_t relu, hipStream_t stream) {
   TrunkArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
               static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
-  return launch_trunk<8, 2>(a, B, stream);
+  // two workgroups per image while that still leaves CUs idle otherwise
+  if (2 * B <= mz::compute_units()) return launch_trunk<8, 2, 2>(a, B, stream);
+  return launch_trunk<8, 2, 1>(a, B, stream);
 }
 int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
                     int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,

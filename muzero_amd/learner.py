@@ -88,9 +88,11 @@ class _Conv3x3Native(torch.autograd.Function):
             need = _lib.lib().mz_conv_wgrad_workspace_bytes(n)
             ws = _wgrad_workspace(need, x.device)
             dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
-            _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gh), _lib.ptr(xh), n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(ws),
-                      ws.numel() * 4, _lib.current_stream())
-        if ctx.needs_input_grad[2]:
+            if ctx.needs_input_grad[2]:      # the bias gradient comes out of the same pass over grad
+                db = torch.empty(256, dtype=torch.float32, device=x.device)
+            _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gh), _lib.ptr(xh), n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db),
+                      _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+        elif ctx.needs_input_grad[2]:
             db = g.sum(dim=(0, 2, 3), dtype=torch.float32)
         return dx, dw, db, None
 

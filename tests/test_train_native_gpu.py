@@ -24,8 +24,11 @@ def test_weight_gradient_kernel_against_torch(N):
     need = _lib.lib().mz_conv_wgrad_workspace_bytes(N)
     ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
     dw = torch.full((256, 256, 3, 3), float("nan"), dtype=torch.float32, device="cuda")
-    _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gd), _lib.ptr(xd), N, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(ws), need,
-              _lib.current_stream())
+    db = torch.full((256,), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gd), _lib.ptr(xd), N, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db),
+              _lib.ptr(ws), need, _lib.current_stream())
+    db_ref = go.double().sum(dim=(0, 1, 2))
+    assert (db.double().cpu() - db_ref).abs().max().item() <= 1e-5 * db_ref.abs().max().item() + 1e-5
     ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double().cuda(), (256, 256, 3, 3),
                                       go.permute(0, 3, 1, 2).double().cuda(), stride=1, padding=1)
     err = (dw.double() - ref).abs().max().item()
