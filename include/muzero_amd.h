@@ -413,6 +413,23 @@ int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream);
 
+/* Training-mode BatchNorm fused with its surroundings in the reference's blocks (ResidualBlock / DownsampleBlock /
+ * DynamicsNetwork, model.py:143-175, :237, as compute_losses runs them, train.py:343, :411):
+ *   y = act( batch_norm(x; batch statistics) [+ residual] ),  act = ReLU when relu != 0
+ * x, residual, y: bf16 [rows][C] (NHWC / channels_last, rows = N*H*W).  Batch mean and biased variance over the
+ * rows (accumulated in double); running_mean / running_var (optional) move by `momentum` with the unbiased
+ * variance as torch.nn.BatchNorm2d does; save_mean / save_invstd float [C] are kept for the backward pass.
+ * Backward: from dy (gradient w.r.t. y), y (for the ReLU mask) and x: dx, dgamma, dbeta and, when dresidual is
+ * given, the gradient of the residual branch (dy masked by the ReLU).  workspace: mz_bn_workspace_bytes(C). */
+int64_t mz_bn_workspace_bytes(int32_t C);
+int mz_bn_relu_train_fwd(const void* x, const void* residual, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
+                         int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd, void* workspace,
+                         int64_t workspace_bytes, mz_stream_t stream);
+int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
+                         const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx, void* dresidual,
+                         float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mz_stream_t stream);
+
 /* ReplayBuffer.sample_batch's draw (model.py:580-588) on device-resident priorities: double prio [n], one per
  * stored position, oldest game first.  u: double [batch], the [0,1) draws np.random.choice would consume.
  * Outputs: flat int32 [batch] = #(cdf <= u) with cdf the normalised cumulative sum of prio / sum(prio)

@@ -81,6 +81,10 @@ _SIGNATURES = {
     "mz_comm_destroy": (C.c_int, [_P]),
     "mz_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32]),
     "mz_conv_wgrad_bf16": (C.c_int, [_P, _P] + [C.c_int32] * 5 + [_P, _P, _P, C.c_int64, _P]),
+    "mz_bn_workspace_bytes": (C.c_int64, [C.c_int32]),
+    "mz_bn_relu_train_fwd": (C.c_int, [_P] * 6 + [C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P,
+                                               C.c_int64, _P]),
+    "mz_bn_relu_train_bwd": (C.c_int, [_P] * 6 + [C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "mz_replay_workspace_bytes": (C.c_int64, [C.c_int64]),
     "mz_replay_sample": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_double, _P, C.c_int32, _P, _P, _P, _P, _P,
                                    C.c_int64, _P]),

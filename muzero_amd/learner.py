@@ -28,6 +28,9 @@ from . import _lib, checkpoint
 
 
 # --------------------------------------------------------------------------- native convolutions
+_PACK_EPOCH = [0]     # bumped at the start of every unrolled forward pass (Learner.losses_from_tensors)
+
+
 class _PackedWeights:
     """Fragment-packed bf16 copies of one convolution's float32 weight (forward form and the
     transposed, mirrored form of the data gradient), repacked on the device when the parameter has
@@ -38,11 +41,13 @@ class _PackedWeights:
 
     def get(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
         from . import mfma
-        key = (weight.data_ptr(), weight._version)
-        slot = self._slots.get(transpose)
         # while a HIP graph of the update is being recorded the packing must be part of it (a replay runs no
-        # Python, so the version check cannot happen then): always pack, into the existing buffer
-        if slot is None or slot[0] != key or torch.cuda.is_current_stream_capturing():
+        # Python, so the version check cannot happen then): pack at the first use in every forward / backward
+        # pass, into the existing buffer - a layer applied at several unroll steps packs once per pass
+        epoch = _PACK_EPOCH[0] if torch.cuda.is_current_stream_capturing() else -1
+        key = (weight.data_ptr(), weight._version, epoch)
+        slot = self._slots.get(transpose)
+        if slot is None or slot[0] != key:
             buf = slot[1] if slot is not None else torch.empty(mfma.packed_elems(256, 256), dtype=torch.bfloat16,
                                                                device=weight.device)
             _lib.call("mz_weights_fold_pack", _lib.ptr(weight.detach()), None, None, None, None, None, 0.0, 256, 256, 256,
@@ -129,6 +134,71 @@ class Conv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+_BN_WS: Dict[tuple, torch.Tensor] = {}
+
+
+def _bn_workspace(C: int, device) -> torch.Tensor:
+    key = (device.type, device.index, C)
+    t = _BN_WS.get(key)
+    if t is None:
+        t = _BN_WS[key] = torch.empty(_lib.lib().mz_bn_workspace_bytes(C) // 8 + 1, dtype=torch.float64, device=device)
+    return t
+
+
+class _BNActNative(torch.autograd.Function):
+    """relu(batch_norm(x) [+ residual]) in training mode on this library's kernels (mz_bn_relu_train_fwd / _bwd).
+    x, residual: bf16 [N, C, H, W] in channels_last memory.  Running statistics are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum):
+        n, c, h, w = x.shape
+        rows = n * h * w
+        y = torch.empty_like(x)                       # keeps the channels_last strides
+        save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        save_invstd = torch.empty_like(save_mean)
+        ws = _bn_workspace(c, x.device)
+        _lib.call("mz_bn_relu_train_fwd", _lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
+                  _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum), 1, rows, c, _lib.ptr(y),
+                  _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
+        ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, save_mean, save_invstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_residual else None
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _bn_workspace(c, x.device)
+        _lib.call("mz_bn_relu_train_bwd", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
+                  _lib.ptr(save_mean), _lib.ptr(save_invstd), 1, n * h * w, c, _lib.ptr(dx), _lib.ptr(dres),
+                  _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
+        return dx, dres, dgamma, dbeta, None, None, None, None
+
+
+def bn_act(bn: nn.BatchNorm2d, x, residual=None):
+    """relu(bn(x) [+ residual]) (model.py:155-158, :166, :237).  The fused kernels serve training-mode BatchNorm on
+    bf16 channels_last activations - what the native convolutions produce - when the learner computes in bf16;
+    everything else goes through torch."""
+    if (getattr(bn, "native", False) and bn.training and x.is_cuda and x.dtype == torch.bfloat16
+            and torch.is_autocast_enabled() and x.dim() == 4 and x.shape[1] in (64, 128, 256, 512)
+            and x.is_contiguous(memory_format=torch.channels_last) and bn.track_running_stats and bn.momentum is not None):
+        with torch.autocast("cuda", enabled=False):
+            if residual is not None:
+                residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            bn.num_batches_tracked.add_(1)
+            return _BNActNative.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                      bn.momentum)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y)
+
+
 # --------------------------------------------------------------------------- modules
 class _Res(nn.Module):
     def __init__(self, c):
@@ -139,8 +209,8 @@ class _Res(nn.Module):
         self.bn2 = nn.BatchNorm2d(c)
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        return F.relu(self.bn2(self.conv2(y)) + x)
+        y = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(y), residual=x)
 
 
 class _Down(nn.Module):
@@ -151,7 +221,7 @@ class _Down(nn.Module):
         self.blocks = nn.ModuleList([_Res(cout) for _ in range(n)])
 
     def forward(self, x):
-        x = F.relu(self.bn(self.conv(x)))
+        x = bn_act(self.bn, self.conv(x))
         for b in self.blocks:
             x = b(x)
         return x
@@ -179,7 +249,7 @@ class _Representation(nn.Module):
         self.resblocks = nn.ModuleList([_Res(c) for _ in range(6)])
 
     def forward(self, x):
-        x = self.downsample(F.relu(self.bn1(self.conv1(x))))
+        x = self.downsample(bn_act(self.bn1, self.conv1(x)))
         for b in self.resblocks:
             x = b(x)
         return x
@@ -199,7 +269,7 @@ class _Dynamics(nn.Module):
         # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
         w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
         x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
-        x = F.relu(self.bn(self.conv_state(x)))
+        x = bn_act(self.bn, self.conv_state(x))
         for b in self.resblocks:
             x = b(x)
         return x, self.reward_head(x.mean(dim=(2, 3)))
@@ -698,7 +768,7 @@ class Learner:
             self.network.load_state_dict(state_dict)
         self.native_convs = bool(native_convs and precision == "bf16" and self.device.type == "cuda")
         for m in self.network.modules():
-            if isinstance(m, Conv3x3):
+            if isinstance(m, (Conv3x3, nn.BatchNorm2d)):
                 m.native = self.native_convs
         self.optimizer = torch.optim.SGD(self.network.parameters(), lr=config.lr_init, momentum=config.momentum,
                                          weight_decay=config.weight_decay)
@@ -754,6 +824,7 @@ class Learner:
         cfg = self.config
         K, S = cfg.num_unroll_steps, cfg.support_size
         dev = self.device
+        _PACK_EPOCH[0] += 1
         f32 = lambda x: torch.as_tensor(x, device=dev).float()
         tv, tr, tp, w = f32(target_values), f32(target_rewards), f32(target_policies), f32(weights)
         act = torch.as_tensor(actions, device=dev).long()

@@ -198,3 +198,44 @@ def test_graphed_update_with_native_convolutions_learns_and_repacks():
     # undo that forward's BatchNorm statistics update? not needed: the reported loss does not depend on them
     got = lrn.update_graphed(*batch)["total_loss"]
     assert abs(got - expect) <= 1e-2 * abs(expect), (got, expect)
+
+
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_fused_batchnorm_relu_against_torch(with_residual):
+    """mz_bn_relu_train_fwd / _bwd through bn_act against torch's BatchNorm2d + add + ReLU in float32 on the same
+    bf16 inputs: output, input / residual / affine gradients, running statistics, batch counter."""
+    import torch.nn as nn
+    from muzero_amd.learner import bn_act
+    torch.manual_seed(3)
+    N, C = 24, 256
+    a, b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        a.weight.uniform_(0.5, 1.5); a.bias.normal_(0, 0.2)
+        a.running_mean.normal_(0, 0.1); a.running_var.uniform_(0.5, 1.5)
+    b.load_state_dict(a.state_dict())
+    a.native = True
+    x = (torch.randn(N, C, 12, 12, device="cuda") * 1.7 + 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(N, C, 12, 12, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    up = torch.randn(N, C, 12, 12, device="cuda")
+    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = bn_act(a, xa, ra if with_residual else None)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous(memory_format=torch.channels_last)
+    (ya.float() * up).sum().backward()
+    xb, rb = x.float().requires_grad_(True), r.float().requires_grad_(True)
+    yb = b(xb)
+    if with_residual:
+        yb = yb + rb
+    yb = torch.relu(yb)
+    # the same upstream gradient as the fused path sees: bf16-rounded
+    (yb * up.to(torch.bfloat16).float()).sum().backward()
+    assert (ya.float() - yb).abs().max().item() <= 1e-2 * yb.abs().max().item()          # bf16 output rounding
+    assert (xa.grad.float() - xb.grad).abs().max().item() <= 2e-2 * xb.grad.abs().max().item()
+    if with_residual:
+        assert (ra.grad.float() - rb.grad).abs().max().item() <= 1e-2 * rb.grad.abs().max().item()
+    # the ReLU masks of the two paths differ where bf16 rounding moves an output across zero: compare the sums loosely
+    assert (a.weight.grad - b.weight.grad).abs().max().item() <= 2e-2 * b.weight.grad.abs().max().item()
+    assert (a.bias.grad - b.bias.grad).abs().max().item() <= 2e-2 * b.bias.grad.abs().max().item()
+    assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-5)
+    assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
