@@ -86,27 +86,58 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, in
   constexpr int D = C::CIN / 3, TPR = C::WIN / 16;  // slots, tiles per image row
   const int xt = (ix0 + 1) / 16;
   constexpr int MAIN = C::IH * D * 6;  // 16-byte units: rows x slots x 6
-  for (int u = tid; u < MAIN; u += C::THREADS) {
+  // every load of the window is in flight before the first LDS write waits for one (loads of rows outside the
+  // image are redirected to row 0 and zeroed afterwards, so that each register is written unconditionally)
+  constexpr int ROUNDS = (MAIN + C::THREADS - 1) / C::THREADS;
+  bf16x8 v[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    int u = tid + i * C::THREADS;
+    u = u < MAIN ? u : MAIN - 1;
     const int row = u / (D * 6), rem = u - row * (D * 6);
     const int s = rem / 6, k = rem - s * 6;
-    const int iy = iy0 + row;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy >= 0 && iy < C::HIN)
-      v = *reinterpret_cast<const bf16x8*>(src + (((long)iy * TPR + xt) * D + s) * 48 + k * 8);
-    char* base = lds + (row * C::IW + 1) * C::ROWB + s * 6;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int el = k * 8 + e, px = el / 3, r = el - px * 3;
-      *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = v[e];
-    }
+    int iy = iy0 + row;
+    iy = (iy >= 0 && iy < C::HIN) ? iy : 0;
+    v[i] = *reinterpret_cast<const bf16x8*>(src + (((long)iy * TPR + xt) * D + s) * 48 + k * 8);
   }
-  for (int u = tid; u < C::IH * C::CIN; u += C::THREADS) {  // halo column x = ix0
+  constexpr int HALO = C::IH * C::CIN;
+  constexpr int HROUNDS = (HALO + C::THREADS - 1) / C::THREADS;
+  __bf16 hv[HROUNDS];
+#pragma unroll
+  for (int i = 0; i < HROUNDS; ++i) {  // halo column x = ix0, from the neighbouring tile element by element
+    int u = tid + i * C::THREADS;
+    u = u < HALO ? u : HALO - 1;
     const int row = u / C::CIN, c = u - row * C::CIN;
     const int s = c / 3, r = c - s * 3;
-    const int iy = iy0 + row;
-    __bf16 v = (__bf16)0.f;
-    if (xt > 0 && iy >= 0 && iy < C::HIN) v = src[(((long)iy * TPR + xt - 1) * D + s) * 48 + 45 + r];
-    *reinterpret_cast<__bf16*>(lds + (row * C::IW) * C::ROWB + c * 2) = v;
+    int iy = iy0 + row;
+    iy = (iy >= 0 && iy < C::HIN) ? iy : 0;
+    hv[i] = src[(((long)iy * TPR + (xt > 0 ? xt - 1 : 0)) * D + s) * 48 + 45 + r];
+  }
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    const int u = tid + i * C::THREADS;
+    if (u < MAIN) {
+      const int row = u / (D * 6), rem = u - row * (D * 6);
+      const int s = rem / 6, k = rem - s * 6;
+      const int iy = iy0 + row;
+      const bool inside = iy >= 0 && iy < C::HIN;
+      char* base = lds + (row * C::IW + 1) * C::ROWB + s * 6;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int el = k * 8 + e, px = el / 3, r = el - px * 3;
+        *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = inside ? v[i][e] : (__bf16)0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HROUNDS; ++i) {
+    const int u = tid + i * C::THREADS;
+    if (u < HALO) {
+      const int row = u / C::CIN, c = u - row * C::CIN;
+      const int iy = iy0 + row;
+      const bool inside = xt > 0 && iy >= 0 && iy < C::HIN;
+      *reinterpret_cast<__bf16*>(lds + (row * C::IW) * C::ROWB + c * 2) = inside ? hv[i] : (__bf16)0.f;
+    }
   }
 }
 
