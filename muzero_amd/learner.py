@@ -828,28 +828,30 @@ class Learner:
         f32 = lambda x: torch.as_tensor(x, device=dev).float()
         tv, tr, tp, w = f32(target_values), f32(target_rewards), f32(target_policies), f32(weights)
         act = torch.as_tensor(actions, device=dev).long()
+        # ONE autocast region around the whole unroll (its cache then casts every float32 weight to bf16 once per
+        # update, not once per unroll step); the losses are computed in float32 with autocast switched off
         amp = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=self.precision == "bf16")
-        with amp:
-            hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
-        policy_logits, value_logits = policy_logits.float(), value_logits.float()
+        f32_math = torch.autocast(dev.type, enabled=False)
         reward_logits = None
         total_v = total_r = total_p = 0.0
         per_sample = 0.0
-        for t in range(K + 1):
-            v_loss = support_ce_loss(value_logits, tv[:, t], S, self.loss_impl)
-            p_loss = -(tp[:, t] * torch.log_softmax(policy_logits, dim=1)).sum(1)
-            r_loss = support_ce_loss(reward_logits, tr[:, t], S, self.loss_impl) if t > 0 \
-                else torch.zeros(tv.shape[0], device=dev)
-            total = cfg.value_loss_weight * v_loss + cfg.reward_loss_weight * r_loss + cfg.policy_loss_weight * p_loss
-            per_sample = per_sample + total * w
-            if t < K:
-                with amp:
+        with amp:
+            hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
+            for t in range(K + 1):
+                with f32_math:
+                    policy_logits, value_logits = policy_logits.float(), value_logits.float()
+                    v_loss = support_ce_loss(value_logits, tv[:, t], S, self.loss_impl)
+                    p_loss = -(tp[:, t] * torch.log_softmax(policy_logits, dim=1)).sum(1)
+                    r_loss = support_ce_loss(reward_logits.float(), tr[:, t], S, self.loss_impl) if t > 0 \
+                        else torch.zeros(tv.shape[0], device=dev)
+                    total = cfg.value_loss_weight * v_loss + cfg.reward_loss_weight * r_loss \
+                        + cfg.policy_loss_weight * p_loss
+                    per_sample = per_sample + total * w
+                    total_v = total_v + v_loss.mean()
+                    total_r = total_r + r_loss.mean()
+                    total_p = total_p + p_loss.mean()
+                if t < K:
                     hidden, reward_logits, policy_logits, value_logits = self.network.recurrent(hidden, act[:, t])
-                reward_logits, policy_logits, value_logits = (reward_logits.float(), policy_logits.float(),
-                                                              value_logits.float())
-            total_v = total_v + v_loss.mean()
-            total_r = total_r + r_loss.mean()
-            total_p = total_p + p_loss.mean()
         total_v = total_v / (K + 1)
         total_p = total_p / (K + 1)
         total_r = total_r / K if K > 0 else torch.zeros(1, device=dev)
