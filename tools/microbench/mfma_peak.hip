@@ -192,6 +192,62 @@ __global__ __launch_bounds__(256, 1) void loop16y(const bf16x8* __restrict__ src
   out[blockIdx.x * 512 + tid] = s;
 }
 
+// the same k-step with the accumulators pinned by hand: 64 of the 72 accumulator tiles in AGPRs (all 256), 8 in
+// VGPRs, every MFMA an inline-asm statement with the register class in its constraint, so that the register
+// allocator cannot shuttle accumulators between the two files
+__device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ void mfma_v(f32x4& acc, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a));
+}
+__global__ __launch_bounds__(256, 1) void loop16z(const bf16x8* __restrict__ src, const void* wts, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 9 * 1024 * 8 / 16; i += blockDim.x) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wts), 0, 74 * 16384, 0x00020000);
+  const int wl = wave * 4096 + lane * 16;
+  auto wf = [&](int off, int nt) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wl + nt * 1024, off, 0)); };
+  constexpr int M = 18;
+  bf16x8 a[9], wq[2][4];
+  for (int i = 0; i < 9; ++i) a[i] = *reinterpret_cast<const bf16x8*>(lds + lane * 16 + i * 1024);
+  for (int p = 0; p < 2; ++p) for (int n = 0; n < 4; ++n) wq[p][n] = wf(p * 16384, n);
+  f32x4 acc[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0, 0, 0, 0};
+  const int off = lane * 16;
+  for (int it = 0; it < iters; it += 8) {
+    int wo = 2 * 16384 + (it % 64) * 16384;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bf16x8 w2[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) w2[n] = wf(wo, n);
+      wo += 16384;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (m < 16) mfma_a(acc[m][n], wq[0][n], a[m % 9]); else mfma_v(acc[m][n], wq[0][n], a[m % 9]);
+        }
+        a[m % 9] = *reinterpret_cast<const bf16x8*>(lds + off + (m % 9) * 1024 + ((k + m / 9) & 7) * 9216);
+      }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) { wq[0][n] = wq[1][n]; wq[1][n] = w2[n]; }
+    }
+  }
+  asm volatile("s_nop 15\n s_nop 15" ::: "memory");  // the asm MFMAs' results are read below: no hazard tracking for inline asm
+  float s = 0;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
 // 4 accumulators of 32x32 (same accumulator registers per wave as 16 of 16x16)
 __global__ __launch_bounds__(512, 2) void loop32(const bf16x8* __restrict__ src, float* out, int iters) {
   const int tid = threadIdx.x;
@@ -226,6 +282,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16w<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16w<18>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16y), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16z), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16x<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16x<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
@@ -237,9 +294,9 @@ int main(int argc, char** argv) {
     for (auto& v : h) v = zero ? 0 : (unsigned short)(0x3c00 + (rand() & 0x83ff));  // |x| in [0.5, 2) with random sign / mantissa
     CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     for (int i = 0; i < 74 * 16384; i += 4096 * 16) CHECK(hipMemcpy((char*)wts + i, h.data(), 74 * 16384 - i < 4096 * 16 ? 74 * 16384 - i : 4096 * 16, hipMemcpyHostToDevice));
-    for (int variant = 0; variant < 8; ++variant) {
+    for (int variant = 0; variant < 9; ++variant) {
       if (variant >= 4 && threads != 512) continue;
-      const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : (variant == 6 ? 36.0 : variant == 7 ? 72.0 : 18.0) * 2 * 16 * 16 * 32;  // per wave
+      const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : (variant == 6 ? 36.0 : variant >= 7 ? 72.0 : 18.0) * 2 * 16 * 16 * 32;  // per wave
       auto launch = [&](int iters) {
         if (variant == 0) hipLaunchKernelGGL(loop16<false>, dim3(cus), dim3(threads), 0, 0, src, out, iters);
         if (variant == 1) hipLaunchKernelGGL(loop16<true>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, out, iters);
@@ -247,6 +304,7 @@ int main(int argc, char** argv) {
         if (variant == 4) hipLaunchKernelGGL(loop16x<5>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 5) hipLaunchKernelGGL(loop16x<6>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 7) hipLaunchKernelGGL(loop16y, dim3(cus), dim3(256), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
+        if (variant == 8) hipLaunchKernelGGL(loop16z, dim3(cus), dim3(256), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 6) hipLaunchKernelGGL(loop16w<18>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 3) hipLaunchKernelGGL(loop16w<9>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
       };
@@ -262,12 +320,13 @@ int main(int argc, char** argv) {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep == 0) iters = (int)(iters * target_ms / ms);
       }
-      const double tf = flop_per_iter * iters * (variant == 7 ? 4.0 : threads / 64.0) * cus / (ms * 1e-3) / 1e12;
-      const char* names[8] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
+      const double tf = flop_per_iter * iters * (variant >= 7 ? 4.0 : threads / 64.0) * cus / (ms * 1e-3) / 1e12;
+      const char* names[9] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
                               "16x16x32 + LDS reads + 2 weight loads per 18",
                               "  64 channels per wave, tiles split 5 / 4", "  64 channels per wave, tiles split 6 / 3",
                               "  two images per pass: 18 tiles per 2 weight loads",
-                              "  two images, 64 channels, one wave per SIMD"};
+                              "  two images, 64 channels, one wave per SIMD",
+                              "  the same, accumulators pinned in AGPRs (asm)"};
       printf("%-46s %-6s data: %7.1f TFLOP/s  (%.1f ms, %d CUs x %d waves)\n", names[variant], zero ? "zero" : "random", tf, ms, cus, threads / 64);
     }
   }
