@@ -10,7 +10,7 @@ from tests.test_oracle_golden import full_cfg
 pytestmark = pytest.mark.gpu
 
 
-def _nets(A):
+def _nets(A, precision="bf16"):
     from muzero_amd.network import MuZeroNetwork
     from oracle import nets as onets
     cfg = full_cfg(A)
@@ -18,7 +18,7 @@ def _nets(A):
     torch.manual_seed(0)
     ref = onets.Net(cfg).eval()
     onets.randomize_bn(ref, seed=1)
-    return cfg, ref, MuZeroNetwork(cfg, precision="bf16", state_dict=ref.state_dict())
+    return cfg, ref, MuZeroNetwork(cfg, precision=precision, state_dict=ref.state_dict())
 
 
 def test_bf16_network_close_to_reference_fixture():
@@ -112,15 +112,15 @@ def test_selfplay_worker_evaluate_mode_and_temperature_zero():
     assert all(v2[i, a] > 0 for i, a in enumerate(actions2.cpu().tolist()))   # only visited actions are drawn
 
 
-@pytest.mark.parametrize("A,B", [(6, 256), (18, 1024), (9, 4096)])
-def test_full_size_search_properties_and_sampled_replay(A, B):
+@pytest.mark.parametrize("A,B,precision", [(6, 256, "bf16"), (18, 1024, "bf16"), (9, 4096, "bf16"), (18, 1024, "bf16x3")])
+def test_full_size_search_properties_and_sampled_replay(A, B, precision):
     """The benchmark configurations at their full sizes: size-independent properties for every game
     (visit counts sum to the simulation count, one node per simulation, no status flags), the
     oracle tree replaying the recorded network outputs bit-exactly for a sample of games, and the
     production one-call search giving the same result as the stepwise one."""
     from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
     from oracle import tree as otree
-    cfg, ref, net = _nets(A)
+    cfg, ref, net = _nets(A, precision)
     sims = 50
     worker = SelfPlayWorker(cfg, net, B, sims, 1)
     env = SyntheticEnv(B, device="cuda", pool=2)
@@ -131,7 +131,7 @@ def test_full_size_search_properties_and_sampled_replay(A, B):
     rng = np.random.default_rng(B)
     sample = rng.choice(B, size=24, replace=False)
     idx = torch.from_numpy(sample).cuda()
-    obs = worker.ring.observation(net.obs_dtype, out=worker.obs)
+    obs = worker.ring.observation(net.obs_dtype, out=worker.obs, pairs=worker.pairs)
     pri0, _ = net.initial_to_pool(obs, m.pool[0])
     p0 = pri0[idx].cpu().numpy()
     m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)
