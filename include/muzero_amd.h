@@ -211,6 +211,14 @@ int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stri
                        int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
                        float* mean_out, int32_t B, mz_stream_t stream);
 
+/* The residual blocks of the first downsample stage (24x24 images, 128 -> 128 channels:
+ * DownsampleBlock.blocks, model.py:167, :173-174; ResidualBlock, model.py:143-159) as one kernel with the
+ * image resident in LDS, every layer written over its own input.  in / out: bf16 NHWC [B][24][24][128];
+ * layers as for mz_conv_chain_bf16 (add_residual on layer l adds the input of layer l - 1, so it cannot be
+ * set on layer 0); n_layers <= 8. */
+int mz_conv_chain_mid_bf16(const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out, int32_t B,
+                           mz_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * float32-accurate networks on the bf16 matrix cores ("bf16x3"): a float32 tensor travels as
  * bf16 pairs hi = bf16(x), lo = bf16(x - hi), laid out [image][2 = hi, lo][pixels][channels], and

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "mz_conv3x3_bf16_info": (C.c_int, [C.c_int32] * 5 + [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mz_conv3x3_bf16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_conv_chain_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "mz_conv_chain_mid_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
     "mz_split_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "mz_join_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "mz_conv3x3_bf16x3": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [_P]),

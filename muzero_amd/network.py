@@ -354,6 +354,17 @@ class MuZeroNetwork:
         return (self.precision in ("bf16", "bf16x3") and H == 12 and W == 12 and 1 <= len(convs) <= 20
                 and all(c.cin == 256 and c.cout == 256 and c.stride == 1 for c in convs))
 
+    def _mid_blocks(self, plan, i, H, W, last) -> int:
+        """Number of consecutive residual blocks from plan[i] on that the fused 24x24x128 kernel
+        (mz_conv_chain_mid_bf16) serves: at most 4 (its 8 layers), never the network's last block (the
+        kernel does not produce the spatial mean)."""
+        n = 0
+        while (self.precision == "bf16" and H == 24 and W == 24 and n < 4 and i + n < len(plan) and i + n != last
+               and plan[i + n][0] == "res"
+               and all(c.cin == 128 and c.cout == 128 and c.stride == 1 for c in plan[i + n][1])):
+            n += 1
+        return n
+
     def _chain(self, key, blocks, first, x, out, in_slot=None, slot_stride=0, actions=None, mean_out=None):
         """[first conv] + residual blocks as ONE kernel (mz_conv_chain_bf16)."""
         cached = self._chains.get(key)
@@ -473,8 +484,12 @@ class MuZeroNetwork:
         fuse = n_tail > 0 and self._chain_ok([c for blk in tail for c in blk], hh, hw)
         head = plan[:len(plan) - n_tail] if fuse else plan
         last = len(plan) - 1
+        skip = 0
         for i, (kind, item) in enumerate(head):
             final = i == last
+            if skip:                   # a residual block that the fused kernel before it already covered
+                skip -= 1
+                continue
             if kind == "conv":
                 HO, WO = (H - 1) // 2 + 1, (W - 1) // 2 + 1
                 y = hidden_out if final else self._buf(("rep", i % 3), self.act_shape(B, HO, WO, item.cout))
@@ -495,6 +510,23 @@ class MuZeroNetwork:
                 else:
                     self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None, weights=w)
                 x, H, W = y, HO, WO
+            elif self._mid_blocks(head, i, H, W, last):
+                # consecutive residual blocks at 24x24x128 (the first downsample stage's): one kernel,
+                # the image resident in LDS
+                n_blk = self._mid_blocks(head, i, H, W, last)
+                skip = n_blk - 1
+                y = self._buf(("rep", i % 3), self.act_shape(B, H, W, item[0].cout))
+                key = ("mid", i)
+                cached = self._chains.get(key)
+                if cached is None:
+                    convs = [c for _, blk in head[i:i + n_blk] for c in blk]
+                    arr = (_lib.ChainLayer * len(convs))()
+                    for j, c in enumerate(convs):
+                        arr[j] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), 1, j % 2)
+                    cached = self._chains[key] = (arr, len(convs))
+                _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(x), cached[0], cached[1], _lib.ptr(y), B,
+                          _lib.current_stream())
+                x = y
             else:
                 c = item[0].cout
                 tmp = self._buf(("rep_tmp", H), self.act_shape(B, H, W, c))

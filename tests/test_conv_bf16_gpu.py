@@ -121,6 +121,68 @@ def test_fused_chain_matches_layer_by_layer():
     np.testing.assert_allclose(mean.cpu().numpy(), last_f32.mean(dim=(1, 2)).numpy(), rtol=5e-3, atol=5e-3 * scale)
 
 
+@pytest.mark.parametrize("B,n_blocks", [(1, 2), (5, 2), (3, 1), (300, 2)])
+def test_mid_chain_matches_layer_by_layer(B, n_blocks):
+    """mz_conv_chain_mid_bf16 (a 24x24x128 image resident in LDS through the residual blocks of the first
+    downsample stage) against the same layers run one kernel at a time (the per-layer kernel adds the
+    block input after the bias, the chain starts its accumulation from it: equal up to one rounding of
+    the float32 sum, i.e. a bf16 ulp here and there) and against a PyTorch fp32 reference of the
+    blocks; more images than compute units (B = 300) makes workgroups take a second image; the result
+    of an image does not depend on the batch it is in, and a repeated launch repeats bit for bit."""
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(11 + B)
+    convs = []
+    for _ in range(2 * n_blocks):
+        w = torch.randn(128, 128, 3, 3, generator=g) / (3 * 128 ** 0.5)
+        b = torch.randn(128, generator=g) * 0.1
+        layer = _Layer()
+        layer.cin, layer.cout, layer.stride = 128, 128, 1
+        layer.dev = {"w": mfma.pack_weights(w, 128).cuda(), "bias": b.cuda()}
+        convs.append((w, b, layer))
+    x0 = torch.randn(B, 24, 24, 128, generator=g).to(torch.bfloat16).cuda()
+    arr = (_lib.ChainLayer * len(convs))()
+    for i, (_, _, layer) in enumerate(convs):
+        arr[i] = _lib.ChainLayer(layer.dev["w"].data_ptr(), layer.dev["bias"].data_ptr(), 1, i % 2)
+
+    def chain(inp):
+        out = torch.empty_like(inp)
+        _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(inp), arr, len(convs), _lib.ptr(out), inp.shape[0],
+                  _lib.current_stream())
+        torch.cuda.synchronize()
+        return out
+
+    out = chain(x0)
+    assert torch.equal(out, chain(x0))
+    if B > 4:
+        assert torch.equal(out[3:5], chain(x0[3:5].contiguous()))
+
+    # one kernel per layer
+    x = x0
+    for j in range(n_blocks):
+        t, y = torch.empty_like(x), torch.empty_like(x)
+        mfma.conv(convs[2 * j][2], x, t, B, 24, 24, True, None, None, 0, None, None, None)
+        mfma.conv(convs[2 * j + 1][2], t, y, B, 24, 24, True, x, None, 0, None, None, None)
+        x = y
+    torch.cuda.synchronize()
+    a, b = out.float(), x.float()
+    scale = b.abs().mean().item()
+    assert ((a - b).abs() <= 0.02 * b.abs() + 0.02 * scale).all(), (a - b).abs().max().item()
+    assert (a != b).float().mean().item() < 0.05          # a few last-bit differences, no more
+
+    # PyTorch fp32 reference with bf16 rounding of the activations between layers
+    n_ref = min(B, 6)
+    rnd = lambda t: t.to(torch.bfloat16).float()
+    conv = lambda t, i: F.conv2d(t.permute(0, 3, 1, 2), rnd(convs[i][0]), convs[i][1], padding=1).permute(0, 2, 3, 1)
+    r = x0[:n_ref].float().cpu()
+    for j in range(n_blocks):
+        t = rnd(F.relu(conv(r, 2 * j)))
+        r = rnd(F.relu(conv(t, 2 * j + 1) + r))
+    got = out[:n_ref].float().cpu()
+    scale = r.abs().mean().item()
+    assert ((got - r).abs() <= 0.02 * r.abs() + 0.02 * scale).all(), (got - r).abs().max().item()
+    assert got.abs().max() > 0
+
+
 # --------------------------------------------------------------- bf16x3: float32-accurate MFMA kernels
 def _split(x):
     hi = x.to(torch.bfloat16)

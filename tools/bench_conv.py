@@ -46,12 +46,53 @@ def bench_chain(n_layers, B, iters):
           f"({ms * 1e3 / n_layers:.1f} us/layer), {flops / ms / 1e9:.1f} TFLOP/s")
 
 
+def bench_mid_chain(B, iters):
+    """The two residual blocks at 24x24x128 as one kernel (mz_conv_chain_mid_bf16) and as four."""
+    from muzero_amd import _lib
+    layers = []
+    for _ in range(4):
+        l = L()
+        l.cin, l.cout, l.stride = 128, 128, 1
+        l.dev = {"w": mfma.pack_weights(torch.randn(128, 128, 3, 3) / 34.0, 128).cuda(), "bias": (torch.randn(128) * 0.1).cuda()}
+        layers.append(l)
+    arr = (_lib.ChainLayer * 4)()
+    for i, l in enumerate(layers):
+        arr[i] = _lib.ChainLayer(l.dev["w"].data_ptr(), l.dev["bias"].data_ptr(), 1, i % 2)
+    x = torch.randn(B, 24, 24, 128, device="cuda").to(torch.bfloat16)
+    t, y, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+
+    def fused():
+        _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(x), arr, 4, _lib.ptr(out), B, _lib.current_stream())
+
+    def layered():
+        mfma.conv(layers[0], x, t, B, 24, 24, True, None, None, 0, None, None, None)
+        mfma.conv(layers[1], t, y, B, 24, 24, True, x, None, 0, None, None, None)
+        mfma.conv(layers[2], y, t, B, 24, 24, True, None, None, 0, None, None, None)
+        mfma.conv(layers[3], t, out, B, 24, 24, True, y, None, 0, None, None, None)
+
+    flops = 2.0 * B * 576 * 128 * 1152 * 4
+    for name, run in (("one kernel", fused), ("four kernels", layered), ("one kernel", fused), ("four kernels", layered)):
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        print(f"24x24x128 x4 layers, {name}, B={B}: {ms * 1e3:.1f} us, {flops / ms / 1e9:.1f} TFLOP/s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="trunk")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
+    if args.shape == "midchain":
+        return bench_mid_chain(args.batch, args.iters)
     if args.shape.startswith("chain"):
         return bench_chain(int(args.shape[5:] or 5), args.batch, args.iters)
     H, cin, cout, stride = SHAPES[args.shape]
