@@ -49,6 +49,8 @@ def test_argument_validation_needs_no_gpu():
         ("mz_conv3x3_f32", (None, None, 0) + (None,) * 6 + (1, 12, 12, 8, 8, 1, 1, None), "null tensor"),
         ("mz_conv3x3_bf16", (None, None, 0) + (None,) * 7 + (1, 12, 12, 256, 256, 1, 1, None), "null tensor"),
         ("mz_conv_chain_bf16", (C.c_void_p(8), None, 0, None, 5, C.c_void_p(8), None, None, None, 4, None), "null"),
+        ("mz_conv_chain_mid_bf16", (C.c_void_p(8), None, 4, C.c_void_p(8), 4, None), "null"),
+        ("mz_conv_chain_mid_bf16", (C.c_void_p(8), C.c_void_p(8), 9, C.c_void_p(8), 4, None), "n_layers"),
         ("mz_heads", (None, 4, 256, 256, 6, 300) + (None,) * 10, "null argument"),
         ("mz_ring_push", (C.c_void_p(8), C.c_void_p(8), 4, 32, 27647, 0, 0, None, None), "multiple of 16"),
         ("mz_ring_to_obs", (C.c_void_p(8), C.c_void_p(8), 1, 4, 32, 9216, 32, None), "outside the ring"),
