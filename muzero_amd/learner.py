@@ -249,6 +249,10 @@ class _Representation(nn.Module):
         self.resblocks = nn.ModuleList([_Res(c) for _ in range(6)])
 
     def forward(self, x):
+        if self.conv1.native and x.is_cuda and torch.is_autocast_enabled():
+            # NHWC bf16 from the first layer on: the library's kernels (and the fused BatchNorm) want it, and
+            # MIOpen's NHWC kernels then run without a layout transpose around every call
+            x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         x = self.downsample(bn_act(self.bn1, self.conv1(x)))
         for b in self.resblocks:
             x = b(x)

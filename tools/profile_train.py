@@ -27,3 +27,10 @@ step = lrn.update_graphed if len(sys.argv) > 4 and sys.argv[4] == "graphed" else
 for _ in range(6):
     step(*args)
 torch.cuda.synchronize()
+if os.environ.get("MZ_TIME_UPDATES"):      # same-box comparisons: milliseconds per update after the warm-up above
+    import time
+    t0 = time.perf_counter()
+    for _ in range(20):
+        step(*args)
+    torch.cuda.synchronize()
+    print(f"{(time.perf_counter() - t0) / 20 * 1e3:.2f} ms per update")
