@@ -414,7 +414,7 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
  * (optional, float [Cout]) = sum over images and pixels of grad_out, from the same pass.  A kernel
  * exists for the 12x12, 256->256 shape (23 of the 31 convolutions); other shapes return MZ_E_ARG.  workspace:
  * caller-owned device memory of at least mz_conv_wgrad_workspace_bytes(B) bytes (partial sums of the image
- * shares).  The matching data gradient is mz_conv3x3_bf16 applied to grad_out with weights packed by
+ * shares); dw and workspace 16-byte aligned.  The matching data gradient is mz_conv3x3_bf16 applied to grad_out with weights packed by
  * mz_weights_fold_pack(transpose = 1) and a zero bias. */
 int64_t mz_conv_wgrad_workspace_bytes(int32_t B);
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,

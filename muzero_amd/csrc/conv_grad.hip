@@ -17,8 +17,8 @@
 // share of the images; its 8 wavefronts split the 128 input channels, each keeping 4 x 9 accumulator
 // tiles (144 registers).  Per image the tile's slices of gout (144 x 64) and of x with a zero halo
 // (14 x 14 x 128) are staged in LDS; the next image travels in registers meanwhile.  Partial sums
-// of the image shares go to a float32 scratch buffer [share][tap][co][ci]; a second kernel adds them
-// up into the reference's [co][ci][ky][kx] layout.
+// of the image shares go to a float32 scratch buffer [share][co][ci][ky][kx] (the reference's layout of
+// dW); a second kernel adds the shares up.
 #include "common.h"
 #include "conv_common.h"
 
@@ -165,38 +165,58 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
       db_partial[share * kCh + co0 + tid] = s;
     }
   }
-  // partial[share][tap][co][ci]: a lane holds rows (co) 4 kq .. 4 kq + 3 of column (ci) lane % 16
+  // partial[share][co][ci][tap] (the layout of dW itself).  A lane holds rows (co) 4 kq .. 4 kq + 3 of column
+  // (ci) lane % 16: for one accumulator row r the wavefront owns, in each of 4 rows of dW, 16 ci x 9 taps = 576
+  // consecutive bytes.  They pass through a wavefront-private piece of LDS (the staging area is free by now; the
+  // first 2 KB may still hold the bias sums) so that they leave as whole 16-byte units of consecutive addresses.
   float* dst = partial + (long)share * 9 * kCh * kCh;
-  const int ci = ci0 + wave * 16 + (lane & 15);
+  float* tr = reinterpret_cast<float*>(lds + 2048) + wave * 576;
+  const int l16 = lane & 15;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dst[((long)t * kCh + co0 + c * 16 + 4 * kq + r) * kCh + ci] = acc[c][t][r];
+      for (int t = 0; t < 9; ++t) tr[kq * 144 + l16 * 9 + t] = acc[c][t][r];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int f = lane + 64 * j;  // float4 index within the 4 x 144 floats
+        if (f < 144) {
+          const int row = f / 36, col4 = f - row * 36;
+          const float4 v = *reinterpret_cast<const float4*>(tr + row * 144 + col4 * 4);
+          const long o = ((long)(co0 + c * 16 + 4 * row + r) * kCh + ci0 + wave * 16) * 9 + col4 * 4;
+          *reinterpret_cast<float4*>(dst + o) = v;
+        }
+      }
+    }
 }
 
-// dW[co][ci][tap] = sum over shares of partial[share][tap][co][ci]; one thread per (co, ci)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int shares,
-                                                          float* __restrict__ dw, const float* __restrict__ db_partial,
+// dW = sum over shares of partial[share], in share order; four consecutive floats per thread
+constexpr int kDw4 = 9 * kCh * kCh / 4;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ partial, int shares,
+                                                          float4* __restrict__ dw, const float* __restrict__ db_partial,
                                                           float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // co * 256 + ci
+  const int i = blockIdx.x * 256 + threadIdx.x;  // the grid covers kDw4 exactly
   if (db && blockIdx.x == 0) {
     float s = 0.f;
     for (int g = 0; g < shares; ++g) s += db_partial[g * kCh + threadIdx.x];
     db[threadIdx.x] = s;
   }
-  float s[9];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* p = partial + i;
+  int g = 0;
+  for (; g + 8 <= shares; g += 8) {  // eight loads in flight per thread
+    float4 v[8];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  for (int g = 0; g < shares; ++g) {
-    const float* p = partial + (long)g * 9 * kCh * kCh + i;
+    for (int k = 0; k < 8; ++k) v[k] = p[(long)(g + k) * kDw4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] += p[(long)t * kCh * kCh];
+    for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
   }
-#pragma unroll
-  for (int t = 0; t < 9; ++t) dw[(long)i * 9 + t] = s[t];
+  for (; g < shares; ++g) {
+    const float4 v = p[(long)g * kDw4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  dw[i] = s;
 }
 
 }  // namespace
@@ -218,6 +238,7 @@ int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream) {
   MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16: null tensor or empty batch");
+  MZ_REQUIRE(((uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "mz_conv_wgrad_bf16: dw and workspace must be 16-byte aligned");
   MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
              "mz_conv_wgrad_bf16: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin, Cout);
   MZ_REQUIRE(workspace_bytes >= mz_conv_wgrad_workspace_bytes(B), "mz_conv_wgrad_bf16: workspace of %lld bytes, %lld needed",
@@ -231,8 +252,9 @@ int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H
   float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * kCh * kCh : nullptr;
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, static_cast<const __bf16*>(grad_out),
                      static_cast<const __bf16*>(x), B, static_cast<float*>(workspace), dbp);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kCh * kCh / 256), dim3(256), 0, s, static_cast<const float*>(workspace),
-                     shares, dw, dbp, dbias);
+  static_assert(kDw4 % 256 == 0, "reduce grid");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kDw4 / 256), dim3(256), 0, s, static_cast<const float4*>(workspace), shares,
+                     reinterpret_cast<float4*>(dw), dbp, dbias);
   return mz::check_launch("mz_conv_wgrad_bf16");
 }
 
