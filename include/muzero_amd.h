@@ -420,6 +420,14 @@ int64_t mz_conv_wgrad_workspace_bytes(int32_t B);
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream);
+/* The same for one layer applied to several batches - the dynamics network's convolutions run once per unroll
+ * step with the same weights (train.py:356-372), and the weight gradient of the update is the sum over the
+ * steps: grad_out[i], x[i] (host arrays of n_segments <= 8 device pointers, B images each) are treated as one
+ * batch of n_segments * B images, so the sum costs one pass and one reduction instead of one per step.
+ * workspace: mz_conv_wgrad_workspace_bytes(n_segments * B). */
+int mz_conv_wgrad_bf16_multi(const void* const* grad_out, const void* const* x, int32_t n_segments, int32_t B,
+                             int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* dw, float* dbias, void* workspace,
+                             int64_t workspace_bytes, mz_stream_t stream);
 
 /* Training-mode BatchNorm fused with its surroundings in the reference's blocks (ResidualBlock / DownsampleBlock /
  * DynamicsNetwork, model.py:143-175, :237, as compute_losses runs them, train.py:343, :411):

@@ -44,9 +44,17 @@ __device__ __forceinline__ s16x4 read_tr(int lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
 }
 
-__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __restrict__ gout,
-                                                           const __bf16* __restrict__ x, int n_images,
-                                                           float* __restrict__ partial,
+// The images may come in several equally sized segments (the same layer applied at several unroll steps:
+// one pass then produces the sum of their weight gradients): image n is image n % seg_images of segment
+// n / seg_images.
+constexpr int kMaxSegments = 8;
+struct WgradSrc {
+  const __bf16* gout[kMaxSegments];
+  const __bf16* x[kMaxSegments];
+  int seg_images;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_images, float* __restrict__ partial,
                                                            float* __restrict__ db_partial) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* gs = lds;
@@ -80,8 +88,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(const __bf16* __rest
   uint4 g0, g1, g2, x0, x1, x2, x3, x4;
 #define MZ_LOAD_IMAGE(n_)                                                      \
   {                                                                            \
-    const __bf16* gi = gout + (long)(n_) * (kPix * kCh) + co0;                 \
-    const __bf16* xi = x + (long)(n_) * (kPix * kCh) + ci0;                    \
+    const int seg_ = (n_) / src.seg_images, in_seg_ = (n_) - seg_ * src.seg_images;  \
+    const __bf16* gi = src.gout[seg_] + (long)in_seg_ * (kPix * kCh) + co0;    \
+    const __bf16* xi = src.x[seg_] + (long)in_seg_ * (kPix * kCh) + ci0;       \
     g0 = *reinterpret_cast<const uint4*>(gi + gs0);                            \
     g1 = *reinterpret_cast<const uint4*>(gi + gs1);                            \
     g2 = *reinterpret_cast<const uint4*>(gi + gs2);                            \
@@ -234,28 +243,56 @@ int64_t mz_conv_wgrad_workspace_bytes(int32_t B) {
   return (int64_t)mz_conv_wgrad_shares(B) * (9 * kCh * kCh + kCh) * 4;  // dW partials, then bias partials
 }
 
-int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
-                       int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
-                       mz_stream_t stream) {
-  MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16: null tensor or empty batch");
-  MZ_REQUIRE(((uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "mz_conv_wgrad_bf16: dw and workspace must be 16-byte aligned");
-  MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
-             "mz_conv_wgrad_bf16: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin, Cout);
-  MZ_REQUIRE(workspace_bytes >= mz_conv_wgrad_workspace_bytes(B), "mz_conv_wgrad_bf16: workspace of %lld bytes, %lld needed",
-             (long long)workspace_bytes, (long long)mz_conv_wgrad_workspace_bytes(B));
+static int wgrad_launch(const WgradSrc& src, int n_images, float* dw, float* dbias, void* workspace,
+                        int64_t workspace_bytes, hipStream_t s, const char* who) {
+  MZ_REQUIRE(((uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "%s: dw and workspace must be 16-byte aligned", who);
+  MZ_REQUIRE(workspace_bytes >= mz_conv_wgrad_workspace_bytes(n_images), "%s: workspace of %lld bytes, %lld needed", who,
+             (long long)workspace_bytes, (long long)mz_conv_wgrad_workspace_bytes(n_images));
   static bool configured[mz::kMaxDevices] = {false};
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_kernel), kWgradLds, configured,
                                       "conv_wgrad"))
     return rc;
-  const int shares = mz_conv_wgrad_shares(B);
-  hipStream_t s = mz::as_stream(stream);
+  const int shares = mz_conv_wgrad_shares(n_images);
   float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * kCh * kCh : nullptr;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, static_cast<const __bf16*>(grad_out),
-                     static_cast<const __bf16*>(x), B, static_cast<float*>(workspace), dbp);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, src, n_images,
+                     static_cast<float*>(workspace), dbp);
   static_assert(kDw4 % 256 == 0, "reduce grid");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kDw4 / 256), dim3(256), 0, s, static_cast<const float4*>(workspace), shares,
                      reinterpret_cast<float4*>(dw), dbp, dbias);
-  return mz::check_launch("mz_conv_wgrad_bf16");
+  return mz::check_launch(who);
+}
+
+int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                       int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+                       mz_stream_t stream) {
+  MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16: null tensor or empty batch");
+  MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
+             "mz_conv_wgrad_bf16: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin, Cout);
+  WgradSrc src{};
+  src.gout[0] = static_cast<const __bf16*>(grad_out);
+  src.x[0] = static_cast<const __bf16*>(x);
+  src.seg_images = B;
+  return wgrad_launch(src, B, dw, dbias, workspace, workspace_bytes, mz::as_stream(stream), "mz_conv_wgrad_bf16");
+}
+
+int mz_conv_wgrad_bf16_multi(const void* const* grad_out, const void* const* x, int32_t n_segments, int32_t B,
+                             int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* dw, float* dbias, void* workspace,
+                             int64_t workspace_bytes, mz_stream_t stream) {
+  MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16_multi: null tensor or empty batch");
+  MZ_REQUIRE(n_segments >= 1 && n_segments <= kMaxSegments, "mz_conv_wgrad_bf16_multi: n_segments = %d outside 1..%d",
+             n_segments, kMaxSegments);
+  MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
+             "mz_conv_wgrad_bf16_multi: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin,
+             Cout);
+  WgradSrc src{};
+  for (int i = 0; i < n_segments; ++i) {
+    MZ_REQUIRE(grad_out[i] && x[i], "mz_conv_wgrad_bf16_multi: segment %d has a null tensor", i);
+    src.gout[i] = static_cast<const __bf16*>(grad_out[i]);
+    src.x[i] = static_cast<const __bf16*>(x[i]);
+  }
+  src.seg_images = B;
+  return wgrad_launch(src, n_segments * B, dw, dbias, workspace, workspace_bytes, mz::as_stream(stream),
+                      "mz_conv_wgrad_bf16_multi");
 }
 
 }  // extern "C"

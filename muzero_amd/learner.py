@@ -19,6 +19,8 @@ broadcast (``muzero_amd.dist.broadcast_state_dict``) and loaded into the inferen
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -38,6 +40,7 @@ class _PackedWeights:
 
     def __init__(self):
         self._slots = {}
+        self.pending = None      # a list while the layer's weight gradients are deferred (see Conv3x3.defer_wgrad)
 
     def get(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
         from . import mfma
@@ -89,7 +92,9 @@ class _Conv3x3Native(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             zero = torch.zeros(256, dtype=torch.float32, device=x.device)
             dx = _Conv3x3Native._conv(gh, ctx.packed.get(weight, True), zero).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.packed.pending is not None:
+            ctx.packed.pending.append((gh, xh))       # summed over the unroll steps by Conv3x3.flush_wgrad
+        elif ctx.needs_input_grad[1]:
             need = _lib.lib().mz_conv_wgrad_workspace_bytes(n)
             ws = _wgrad_workspace(need, x.device)
             dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
@@ -124,6 +129,36 @@ class Conv3x3(nn.Conv2d):
     def __init__(self, cin, cout, stride=1):
         super().__init__(cin, cout, 3, stride, 1)
         self._packed = _PackedWeights()
+
+    def defer_wgrad(self, on: bool = True) -> None:
+        """A layer applied at several unroll steps (the dynamics network's): its backward passes only record
+        their (grad_out, x) pairs, and ``flush_wgrad`` - called once after ``loss.backward()`` - turns all of
+        them into the weight and bias gradients with ONE kernel pass (mz_conv_wgrad_bf16_multi)."""
+        self._packed.pending = [] if on else None
+
+    def flush_wgrad(self) -> None:
+        pend = self._packed.pending
+        if not pend:
+            return
+        self._packed.pending = []
+        dev = self.weight.device
+        k = 0
+        while k < len(pend):
+            n = pend[k][0].shape[0]
+            seg = [pend[k]]
+            while len(seg) < 8 and k + len(seg) < len(pend) and pend[k + len(seg)][0].shape[0] == n:
+                seg.append(pend[k + len(seg)])
+            k += len(seg)
+            gp = (C.c_void_p * len(seg))(*[g.data_ptr() for g, _ in seg])
+            xp = (C.c_void_p * len(seg))(*[x.data_ptr() for _, x in seg])
+            ws = _wgrad_workspace(_lib.lib().mz_conv_wgrad_workspace_bytes(n * len(seg)), dev)
+            dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=dev)
+            db = torch.empty(256, dtype=torch.float32, device=dev)
+            _lib.call("mz_conv_wgrad_bf16_multi", gp, xp, len(seg), n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db),
+                      _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+            for p, g in ((self.weight, dw), (self.bias, db)):
+                if p.requires_grad:
+                    p.grad = g if p.grad is None else p.grad + g
 
     def forward(self, x):
         if (self.native and x.is_cuda and torch.is_autocast_enabled() and self.stride == (1, 1)
@@ -893,7 +928,7 @@ class Learner:
                 v, r, p, per = self.losses_from_tensors(*static)
                 loss = per.mean()
                 self.optimizer.zero_grad(set_to_none=True)
-                loss.backward()
+                self._backward(loss)
                 torch.nn.utils.clip_grad_norm_(self.network.parameters(), self.config.max_grad_norm)
                 self.optimizer.step()
                 return torch.stack([v.detach().reshape(()), r.detach().reshape(()), p.detach().reshape(()), loss.detach()]), per.detach()
@@ -925,10 +960,24 @@ class Learner:
         return {"value_loss": float(m[0]), "reward_loss": float(m[1]), "policy_loss": float(m[2]),
                 "total_loss": float(m[3]), "priorities": per.cpu().numpy()}
 
+    def _backward(self, loss) -> None:
+        """loss.backward() with the weight gradients of the dynamics network's native convolutions - applied
+        once per unroll step - computed by one kernel pass per layer over all steps instead of one per step."""
+        convs = [m for m in self.network.dynamics.modules() if isinstance(m, Conv3x3)] if self.native_convs else []
+        for m in convs:
+            m.defer_wgrad(True)
+        try:
+            loss.backward()
+            for m in convs:
+                m.flush_wgrad()
+        finally:
+            for m in convs:
+                m.defer_wgrad(False)
+
     def _step(self, v, r, p, per):
         loss = per.mean()
         self.optimizer.zero_grad()
-        loss.backward()
+        self._backward(loss)
         if self.data_parallel:
             from . import dist as mzdist
             mzdist.average_gradients(self.network.parameters())     # one all-reduce per update

@@ -239,3 +239,69 @@ def test_fused_batchnorm_relu_against_torch(with_residual):
     assert torch.allclose(a.running_mean, b.running_mean, rtol=1e-4, atol=1e-5)
     assert torch.allclose(a.running_var, b.running_var, rtol=1e-4, atol=1e-5)
     assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 1
+
+
+def test_wgrad_over_several_segments_equals_the_sum_of_single_calls():
+    """mz_conv_wgrad_bf16_multi on three (grad_out, x) pairs = the sum of three mz_conv_wgrad_bf16 calls, up to the
+    order of the float32 partial sums; bias gradient included."""
+    import ctypes as C
+    from muzero_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n, segs = 24, 3
+    gs = [torch.randn(n, 12, 12, 256, generator=g).to(torch.bfloat16).cuda() for _ in range(segs)]
+    xs = [torch.randn(n, 12, 12, 256, generator=g).to(torch.bfloat16).cuda() for _ in range(segs)]
+    ws = torch.empty(_lib.lib().mz_conv_wgrad_workspace_bytes(n * segs) // 4, device="cuda")
+    dw, db = torch.empty(256, 256, 3, 3, device="cuda"), torch.empty(256, device="cuda")
+    gp = (C.c_void_p * segs)(*[t.data_ptr() for t in gs])
+    xp = (C.c_void_p * segs)(*[t.data_ptr() for t in xs])
+    _lib.call("mz_conv_wgrad_bf16_multi", gp, xp, segs, n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+              ws.numel() * 4, _lib.current_stream())
+    sum_w, sum_b = torch.zeros_like(dw), torch.zeros_like(db)
+    for gi, xi in zip(gs, xs):
+        w1, b1 = torch.empty_like(dw), torch.empty_like(db)
+        _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gi), _lib.ptr(xi), n, 12, 12, 256, 256, _lib.ptr(w1), _lib.ptr(b1),
+                  _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+        sum_w += w1
+        sum_b += b1
+    torch.cuda.synchronize()
+    scale = sum_w.abs().max().item()
+    assert scale > 1.0
+    assert (dw - sum_w).abs().max().item() <= 2e-5 * scale
+    assert (db - sum_b).abs().max().item() <= 2e-5 * sum_b.abs().max().item()
+    with pytest.raises(_lib.MuZeroAmdError, match="n_segments"):
+        _lib.call("mz_conv_wgrad_bf16_multi", gp, xp, 9, n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+                  ws.numel() * 4, _lib.current_stream())
+
+
+def test_deferred_weight_gradients_equal_the_per_step_ones():
+    """Learner._backward (the dynamics convolutions' weight gradients from one kernel pass over all unroll steps)
+    against a plain loss.backward() (one pass per step, summed by autograd) on the same network and batch."""
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.learner import Learner
+    from muzero_amd.network import init_state_dict
+    cfg = MuZeroConfig()
+    cfg.observation_shape, cfg.action_space_size = (96, 96, 96), 6
+    sd = init_state_dict(cfg, seed=1)
+    rng = np.random.default_rng(1)
+    B, K, A = 8, cfg.num_unroll_steps, 6
+    batch = (torch.from_numpy(rng.random((B, 96, 96, 96), dtype=np.float32)), rng.integers(0, A, (B, K)),
+             rng.normal(0, 3, (B, K + 1)), rng.normal(0, 1, (B, K + 1)), rng.dirichlet(np.ones(A), (B, K + 1)), np.ones(B))
+    grads = []
+    for deferred in (False, True):
+        lrn = Learner(cfg, state_dict=sd, precision="bf16", native_convs=True)
+        loss = lrn.losses_from_tensors(*batch)[3].mean()
+        if deferred:
+            lrn._backward(loss)
+        else:
+            loss.backward()
+        grads.append({k: p.grad.detach().float().clone() for k, p in lrn.network.named_parameters()})
+    plain, fused = grads
+    assert plain.keys() == fused.keys()
+    for k in plain:
+        scale = plain[k].abs().max().item()
+        # the dynamics convolutions differ by the order of the float32 partial sums only; layers further back inherit
+        # that difference through bf16 activations' gradients, and MIOpen's split-K weight gradients (atomics) do
+        # not repeat bit for bit between two runs anyway
+        tol = 1e-4 if k.startswith("dynamics.") and ("conv_state" in k or "resblocks" in k) and "conv" in k else 3e-2
+        err = (plain[k] - fused[k]).abs().max().item()
+        assert err <= tol * scale, (k, err, scale)
