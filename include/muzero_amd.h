@@ -316,16 +316,17 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 
-/* Rotating, tiled form of the stacked observation: obs (bf16 or float)
- * [B][H][W/16][D][16][3] holds, for row y and 16-pixel tile of x, frame slot s as one run of
- * 16 pixels x 3 values; this call writes frames uint8 [B][HW][3], normalised by /255, into
- * slot `slot` (all D slots when fill_all != 0, or for the games flagged in the optional
- * fill_mask int32 [B]: the reset rule, train.py:49-50).  W must be a
- * multiple of 16.  With `newest` the last slot written, slot s holds what CustomFrameStack's
- * output (train.py:62-63) has at channels 3*((s - newest - 1) mod D) + {0,1,2}; a consumer
- * (mz_conv3x3_bf16_rot) reads it through input-channel weights permuted the same way. */
-int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
-                      int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream);
+/* Rotating, tiled form of the stacked observation: obs (bf16 or float) [B][H][W/16][D][56] holds, for row y
+ * and 16-pixel tile of x, frame slot s as one run of 17 pixels x 3 values + 5 values of padding: the last pixel
+ * of the tile to the left (zero for a row's first tile) followed by the tile's 16 pixels.  This call writes
+ * frames uint8 [B][H*W][3], normalised by /255, into slot `slot` (all D slots when fill_all != 0, or for the
+ * games flagged in the optional fill_mask int32 [B]: the reset rule, train.py:49-50).  The buffer must have
+ * been zero-filled once (the first tile's halo and the padding are never written).  W must be a multiple of 16.
+ * With `newest` the last slot written, slot s holds what CustomFrameStack's output (train.py:62-63) has at
+ * channels 3*((s - newest - 1) mod D) + {0,1,2}; a consumer (mz_conv3x3_bf16_rot) reads it through
+ * input-channel weights permuted the same way. */
+int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t H,
+                      int32_t W, int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream);
 
 /* prepare_observation (train.py:529-540) for a batch: uint8 NHWC [B][HW][C]
  * -> float32 NCHW [B][C][HW], x / 255 (bit-identical to the float64 divide

@@ -68,8 +68,7 @@ _SIGNATURES = {
     "mz_ring_to_obs": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_conv3x3_bf16_rot": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mz_conv3x3_bf16_rot_sel": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P]),
-    "mz_obs_slot_write": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
-                                    _P]),
+    "mz_obs_slot_write": (C.c_int, [_P, _P] + [C.c_int32] * 7 + [_P, _P]),
     "mz_gather_stacked_obs": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mz_prepare_observation": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_packed_conv_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -76,16 +76,17 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
   }
 }
 
-// The same window from the rotating, tiled observation [H][W/16][D][16][3] (prep.hip): the
-// patch's 16 output-stride columns are exactly one 16-pixel tile, whose D runs of 96 bytes are
-// read with 16-byte loads and scattered to [pixel][3*D channels] in LDS two bytes at a time;
-// the one halo column on the left comes from the neighbouring tile element by element.
+// The same window from the rotating, tiled observation [H][W/16][D][56] (prep.hip): the patch's 17 input
+// columns - 16 output-stride columns and the one to their left - are exactly one tile's runs (halo pixel, 16
+// pixels, padding: 7 units of 16 bytes per slot), read with 16-byte loads and scattered to
+// [pixel][3*D channels] in LDS two bytes at a time.
 template <class C>
 __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, int iy0, int ix0, int tid) {
   static_assert(C::IW == 17 && C::CIN % 3 == 0 && C::CINC == C::CIN && C::WIN % 16 == 0, "tile = patch width");
   constexpr int D = C::CIN / 3, TPR = C::WIN / 16;  // slots, tiles per image row
+  constexpr int RUN = 56, UPS = RUN / 8;            // values and 16-byte units per slot run
   const int xt = (ix0 + 1) / 16;
-  constexpr int MAIN = C::IH * D * 6;  // 16-byte units: rows x slots x 6
+  constexpr int MAIN = C::IH * D * UPS;  // 16-byte units: rows x slots x 7
   // every load of the window is in flight before the first LDS write waits for one (loads of rows outside the
   // image are redirected to row 0 and zeroed afterwards, so that each register is written unconditionally)
   constexpr int ROUNDS = (MAIN + C::THREADS - 1) / C::THREADS;
@@ -94,49 +95,25 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, in
   for (int i = 0; i < ROUNDS; ++i) {
     int u = tid + i * C::THREADS;
     u = u < MAIN ? u : MAIN - 1;
-    const int row = u / (D * 6), rem = u - row * (D * 6);
-    const int s = rem / 6, k = rem - s * 6;
+    const int row = u / (D * UPS), rem = u - row * (D * UPS);   // rem = slot * 7 + unit: the row's runs are contiguous
     int iy = iy0 + row;
     iy = (iy >= 0 && iy < C::HIN) ? iy : 0;
-    v[i] = *reinterpret_cast<const bf16x8*>(src + (((long)iy * TPR + xt) * D + s) * 48 + k * 8);
-  }
-  constexpr int HALO = C::IH * C::CIN;
-  constexpr int HROUNDS = (HALO + C::THREADS - 1) / C::THREADS;
-  __bf16 hv[HROUNDS];
-#pragma unroll
-  for (int i = 0; i < HROUNDS; ++i) {  // halo column x = ix0, from the neighbouring tile element by element
-    int u = tid + i * C::THREADS;
-    u = u < HALO ? u : HALO - 1;
-    const int row = u / C::CIN, c = u - row * C::CIN;
-    const int s = c / 3, r = c - s * 3;
-    int iy = iy0 + row;
-    iy = (iy >= 0 && iy < C::HIN) ? iy : 0;
-    hv[i] = src[(((long)iy * TPR + (xt > 0 ? xt - 1 : 0)) * D + s) * 48 + 45 + r];
+    v[i] = *reinterpret_cast<const bf16x8*>(src + ((long)iy * TPR + xt) * (D * RUN) + rem * 8);
   }
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
     const int u = tid + i * C::THREADS;
     if (u < MAIN) {
-      const int row = u / (D * 6), rem = u - row * (D * 6);
-      const int s = rem / 6, k = rem - s * 6;
+      const int row = u / (D * UPS), rem = u - row * (D * UPS);
+      const int s = rem / UPS, k = rem - s * UPS;
       const int iy = iy0 + row;
       const bool inside = iy >= 0 && iy < C::HIN;
-      char* base = lds + (row * C::IW + 1) * C::ROWB + s * 6;
+      char* base = lds + (row * C::IW) * C::ROWB + s * 6;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int el = k * 8 + e, px = el / 3, r = el - px * 3;
-        *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = inside ? v[i][e] : (__bf16)0.f;
+        if (el < 51) *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = inside ? v[i][e] : (__bf16)0.f;
       }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < HROUNDS; ++i) {
-    const int u = tid + i * C::THREADS;
-    if (u < HALO) {
-      const int row = u / C::CIN, c = u - row * C::CIN;
-      const int iy = iy0 + row;
-      const bool inside = xt > 0 && iy >= 0 && iy < C::HIN;
-      *reinterpret_cast<__bf16*>(lds + (row * C::IW) * C::ROWB + c * 2) = inside ? hv[i] : (__bf16)0.f;
     }
   }
 }
@@ -150,7 +127,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   const int b = blockIdx.x / (C::PY * C::PX), patch = blockIdx.x % (C::PY * C::PX);
   const int oy0 = (patch / C::PX) * C::TH, ox0 = (patch % C::PX) * C::TW;
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
-  const __bf16* src = a.in + img * (long)C::HIN * C::WIN * C::CIN;
+  // elements per image: NHWC, or the rotating layout's runs of 56 values per (row, 16-pixel tile, slot)
+  constexpr long kImage = ROT ? (long)C::HIN * (C::WIN / 16) * (C::CIN / 3) * 56 : (long)C::HIN * C::WIN * C::CIN;
+  const __bf16* src = a.in + img * kImage;
   const float* av = a.avec ? a.avec + (long)a.actions[b] * C::CIN : nullptr;
   const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;
   const int r16 = lane & 15, kq = lane >> 4;

@@ -114,15 +114,19 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
   }
 }
 
-// Rotating observation: obs [B][H][W/16][D][16][3] keeps, for every row y and 16-pixel tile of
-// x, frame slot s as one run of 16 pixels x 3 values (96 bytes in bf16), so a new frame is written
-// as whole 32-byte sectors and costs 3 values per pixel instead of rebuilding the stack (the
-// consumer gathers a pixel's 3*D values from the D runs of its tile and undoes the rotation by
-// permuting its input-channel weights).  One thread per pixel; fill_all writes the frame into
-// every slot (the reset rule, train.py:49-50).
+// Rotating observation: obs [B][H][W/16][D][56] keeps, for every row y and 16-pixel tile of x, frame slot s as
+// one run of 17 pixels x 3 values + 5 values of padding (112 bytes in bf16): the tile's 16 pixels preceded by
+// the LAST pixel of the tile to its left (zero for the first tile of a row).  A stride-2 convolution's 8-output
+// patch needs exactly these 17 columns, so its input window is D whole runs per row and no pixel has to be
+// fetched from a neighbouring tile.  A new frame costs 3 (+ 3/16) values per pixel instead of rebuilding the
+// stack (the consumer gathers a pixel's 3*D values from the D runs of its tile and undoes the rotation by
+// permuting its input-channel weights).  One thread per pixel; fill_all writes the frame into every slot
+// (the reset rule, train.py:49-50).  Halo of the first tile and padding are never written: the caller
+// provides the buffer zero-filled.
+constexpr int kRotRun = 56;
 template <typename OutT>
 __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
-                                                            OutT* __restrict__ obs, int D, int HW, int slot,
+                                                            OutT* __restrict__ obs, int D, int HW, int W, int slot,
                                                             int fill_all, const int* __restrict__ fill_mask) {
   const int b = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;  // pixel index y*W + x; W is a multiple of 16
@@ -136,15 +140,25 @@ __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char
     if constexpr (sizeof(OutT) == 2) v[r] = f32_to_bf16_rne(x);
     else v[r] = x;
   }
-  // (y, x/16) = p / 16 enumerates the tiles in memory order
-  OutT* o = obs + (((long)b * (HW / 16) + p / 16) * D) * 48 + (p % 16) * 3;
+  // (y, x/16) = p / 16 enumerates the tiles in memory order; the pixel is element px + 1 of its own tile's
+  // run and, when it is its tile's last, element 0 of the next tile's (same row)
+  const int px = p % 16;
+  OutT* o = obs + (((long)b * (HW / 16) + p / 16) * D) * kRotRun + (px + 1) * 3;
+  const bool also_halo = px == 15 && (p % W) != W - 1;
+  const long halo = (long)D * kRotRun - 16 * 3;  // from own element to element 0 of the next tile's run
   if (fill_all) {
     for (int d = 0; d < D; ++d)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) o[d * 48 + r] = v[r];
+      for (int r = 0; r < 3; ++r) {
+        o[d * kRotRun + r] = v[r];
+        if (also_halo) o[d * kRotRun + halo + r] = v[r];
+      }
   } else {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) o[slot * 48 + r] = v[r];
+    for (int r = 0; r < 3; ++r) {
+      o[slot * kRotRun + r] = v[r];
+      if (also_halo) o[slot * kRotRun + halo + r] = v[r];
+    }
   }
 }
 
@@ -232,18 +246,19 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
   return mz::check_launch("mz_ring_to_obs");
 }
 
-int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
-                      int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream) {
-  MZ_REQUIRE(frames && obs && B > 0 && D > 0 && HW > 0 && B <= 65535, "mz_obs_slot_write: bad arguments");
-  MZ_REQUIRE(HW % 16 == 0, "mz_obs_slot_write: the image width must be a multiple of 16 (HW = %d)", HW);
+int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int32_t B, int32_t D, int32_t H,
+                      int32_t W, int32_t slot, int32_t fill_all, const int32_t* fill_mask, mz_stream_t stream) {
+  MZ_REQUIRE(frames && obs && B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535, "mz_obs_slot_write: bad arguments");
+  MZ_REQUIRE(W % 16 == 0, "mz_obs_slot_write: the image width must be a multiple of 16 (W = %d)", W);
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
+  const int HW = H * W;
   const dim3 grid((HW + 255) / 256, B);
   if (out_is_bf16)
     hipLaunchKernelGGL(obs_slot_write_kernel<unsigned short>, grid, dim3(256), 0, mz::as_stream(stream), frames,
-                       static_cast<unsigned short*>(obs), D, HW, slot, fill_all, fill_mask);
+                       static_cast<unsigned short*>(obs), D, HW, W, slot, fill_all, fill_mask);
   else
     hipLaunchKernelGGL(obs_slot_write_kernel<float>, grid, dim3(256), 0, mz::as_stream(stream), frames,
-                       static_cast<float*>(obs), D, HW, slot, fill_all, fill_mask);
+                       static_cast<float*>(obs), D, HW, W, slot, fill_all, fill_mask);
   return mz::check_launch("mz_obs_slot_write");
 }
 

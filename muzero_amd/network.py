@@ -449,9 +449,10 @@ class MuZeroNetwork:
         """obs_nhwc [B,H,W,Cin] (activation dtype) -> hidden_out [B,h,w,W], mean_out float32 [B,W].
         rotation: newest slot of an observation in rotating form (None = reference channel order)."""
         rot_kernel = False
-        if rotation is not None:   # [B, H, W/16, D, 16, 3], see prep.FrameRing.enable_rotating
-            if obs_nhwc.dim() != 6 or obs_nhwc.shape[3] * 3 != self.cin:
-                raise ValueError("a rotating observation is [B, H, W/16, frames, 16, 3]")
+        if rotation is not None:   # [B, H, W/16, D, 56], see prep.FrameRing.enable_rotating
+            from .prep import ROT_RUN
+            if obs_nhwc.dim() != 5 or obs_nhwc.shape[3] * 3 != self.cin or obs_nhwc.shape[4] != ROT_RUN:
+                raise ValueError("a rotating observation is [B, H, W/16, frames, 56]")
             B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2] * 16
             _lib.expect(obs_nhwc, "observation", self.obs_dtype)
             first = self.rep_plan[0][1]

@@ -33,20 +33,21 @@ class FrameRing:
         return self.staging
 
     def enable_rotating(self, dtype=torch.bfloat16) -> None:
-        """Also keep the stacked observation in rotating, tiled form [B, H, W/16, depth, 16, 3]:
-        a push rewrites only the newest slot (3 values per pixel, as whole 96-byte runs, instead
-        of the whole stack).  Call before ``reset``."""
+        """Also keep the stacked observation in rotating, tiled form [B, H, W/16, depth, 56] (per row, 16-pixel
+        tile and slot: the last pixel of the tile to the left, the tile's 16 pixels, 5 values of padding; see
+        mz_obs_slot_write): a push rewrites only the newest slot (3 values per pixel instead of the whole
+        stack).  Call before ``reset``."""
         if dtype not in (torch.bfloat16, torch.float32):
             raise ValueError("observation dtype must be bfloat16 or float32")
         if self.W % 16:
             raise ValueError("the rotating observation needs an image width that is a multiple of 16")
-        self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, 16, 3, dtype=dtype, device=self.device)
+        self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, ROT_RUN, dtype=dtype, device=self.device)
         self.newest_dev = torch.full((1,), self.newest, dtype=torch.int32, device=self.device)   # for graph replay
 
     def _write_rot(self, src: torch.Tensor, fill_all: int, mask: torch.Tensor = None) -> None:
         if self.rot is not None:
             _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), 1 if self.rot.dtype == torch.bfloat16 else 0,
-                      self.B, self.depth, self.H * self.W, self.newest, fill_all, _lib.ptr(mask), _lib.current_stream())
+                      self.B, self.depth, self.H, self.W, self.newest, fill_all, _lib.ptr(mask), _lib.current_stream())
             self.newest_dev.fill_(self.newest)
 
     def reset(self, frames: torch.Tensor) -> None:
@@ -71,7 +72,7 @@ class FrameRing:
         self._write_rot(src, 0, mask)
 
     def rotating_observation(self):
-        """(tensor [B, H, W/16, depth, 16, 3], newest slot): slot s holds channels
+        """(tensor [B, H, W/16, depth, 56], newest slot): slot s holds channels
         3*((s - newest - 1) mod depth) + {0, 1, 2} of ``observation()``."""
         if self.rot is None:
             raise ValueError("enable_rotating() was not called")
@@ -99,10 +100,15 @@ class FrameRing:
         return out
 
 
+ROT_RUN = 56     # values per (row, tile, slot) run of the rotating observation: 17 pixels x 3 + 5 of padding
+
+
 def untile(rot: torch.Tensor) -> torch.Tensor:
-    """[B, H, W/16, D, 16, 3] -> NHWC [B, H, W, 3*D] with the channels still in slot order."""
-    B, H, T, D, _, _ = rot.shape
-    return rot.permute(0, 1, 2, 4, 3, 5).reshape(B, H, T * 16, 3 * D)
+    """[B, H, W/16, D, 56] -> NHWC [B, H, W, 3*D] with the channels still in slot order (the halo pixel and
+    the padding of every run dropped)."""
+    B, H, T, D, _ = rot.shape
+    own = rot[..., 3:51].reshape(B, H, T, D, 16, 3)
+    return own.permute(0, 1, 2, 4, 3, 5).reshape(B, H, T * 16, 3 * D)
 
 
 def rotation_permutation(depth: int, newest: int) -> torch.Tensor:

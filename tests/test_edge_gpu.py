@@ -205,6 +205,7 @@ def test_rotating_observation_equals_the_stacked_one():
         true = ring.observation(torch.bfloat16)
         perm = ring.rotation_permutation().cuda()
         assert torch.equal(true[..., perm], untile(rot))
+        _check_rot_halo(rot)
         h_true = torch.empty(B, 12, 12, 256, dtype=torch.bfloat16, device="cuda")
         h_rot = torch.empty_like(h_true)
         mean = torch.empty(B, 256, dtype=torch.float32, device="cuda")
@@ -239,6 +240,15 @@ def test_per_game_restart_refills_only_the_flagged_stacks():
     rot, newest = ring.rotating_observation()
     perm = ring.rotation_permutation().cuda()
     assert torch.equal(ring.observation(torch.bfloat16)[..., perm], untile(rot))
+    _check_rot_halo(rot)
+
+
+def _check_rot_halo(rot):
+    """Every (row, tile, slot) run of the rotating observation starts with the last pixel of the tile to its
+    left (zero for a row's first tile) and ends with five values of padding that stay zero."""
+    assert rot.shape[-1] == 56
+    assert torch.equal(rot[:, :, 1:, :, 0:3], rot[:, :, :-1, :, 48:51])
+    assert not rot[:, :, 0, :, 0:3].any() and not rot[..., 51:].any()
 
 
 def test_graph_replay_of_the_rotating_path_and_stale_graph_guard():

@@ -46,6 +46,30 @@ def bench_chain(n_layers, B, iters):
           f"({ms * 1e3 / n_layers:.1f} us/layer), {flops / ms / 1e9:.1f} TFLOP/s")
 
 
+def bench_stem_rot(B, iters):
+    """The first convolution on the rotating, tiled observation (mz_conv3x3_bf16_rot)."""
+    from muzero_amd import _lib
+    w = mfma.pack_weights(torch.randn(256, 96, 3, 3) / 29.0, 96).cuda()
+    b = (torch.randn(256) * 0.1).cuda()
+    x = torch.rand(B, 96, 6, 32, 56, device="cuda").to(torch.bfloat16)
+    out = torch.empty(B, 48, 48, 256, dtype=torch.bfloat16, device="cuda")
+    run = lambda: _lib.call("mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(out), B, 1,
+                            _lib.current_stream())
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * B * 2304 * 256 * 864
+    print(f"first convolution, rotating observation, B={B}: {ms * 1e3:.1f} us, {flops / ms / 1e9:.1f} TFLOP/s, "
+          f"{(x.numel() + out.numel()) * 2 / ms / 1e9:.2f} TB/s of input + output")
+
+
 def bench_mid_chain(B, iters):
     """The two residual blocks at 24x24x128 as one kernel (mz_conv_chain_mid_bf16) and as four."""
     from muzero_amd import _lib
@@ -91,6 +115,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
+    if args.shape == "stemrot":
+        return bench_stem_rot(args.batch, args.iters)
     if args.shape == "midchain":
         return bench_mid_chain(args.batch, args.iters)
     if args.shape.startswith("chain"):
