@@ -183,6 +183,41 @@ def test_mid_chain_matches_layer_by_layer(B, n_blocks):
     assert got.abs().max() > 0
 
 
+def test_mid_chain_layer_options():
+    """mz_conv_chain_mid_bf16 with a single layer, with eight layers (its maximum), and with a layer that has no
+    ReLU (negative outputs survive into the next layer's input), each against the per-layer kernel."""
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(21)
+    B = 4
+    layers = []
+    for _ in range(8):
+        layer = _Layer()
+        layer.cin, layer.cout, layer.stride = 128, 128, 1
+        layer.dev = {"w": mfma.pack_weights(torch.randn(128, 128, 3, 3, generator=g) / (3 * 128 ** 0.5), 128).cuda(),
+                     "bias": (torch.randn(128, generator=g) * 0.1).cuda()}
+        layers.append(layer)
+    x0 = torch.randn(B, 24, 24, 128, generator=g).to(torch.bfloat16).cuda()
+    for specs in ([(1, 0)], [(0, 0), (1, 0), (1, 1)], [(1, 0), (1, 1)] * 4):       # (relu, add_residual) per layer
+        arr = (_lib.ChainLayer * len(specs))()
+        for i, (relu, res) in enumerate(specs):
+            arr[i] = _lib.ChainLayer(layers[i].dev["w"].data_ptr(), layers[i].dev["bias"].data_ptr(), relu, res)
+        out = torch.empty_like(x0)
+        _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(x0), arr, len(specs), _lib.ptr(out), B, _lib.current_stream())
+        x, prev = x0, None
+        for i, (relu, res) in enumerate(specs):
+            y = torch.empty_like(x)
+            mfma.conv(layers[i], x, y, B, 24, 24, bool(relu), prev if res else None, None, 0, None, None, None)
+            prev, x = x, y
+        torch.cuda.synchronize()
+        a, b = out.float(), x.float()
+        scale = b.abs().mean().item()
+        assert ((a - b).abs() <= 0.03 * b.abs() + 0.03 * scale).all(), (len(specs), (a - b).abs().max().item())
+    with pytest.raises(_lib.MuZeroAmdError, match="block input"):
+        arr = (_lib.ChainLayer * 1)()
+        arr[0] = _lib.ChainLayer(layers[0].dev["w"].data_ptr(), layers[0].dev["bias"].data_ptr(), 1, 1)
+        _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(x0), arr, 1, _lib.ptr(torch.empty_like(x0)), B, _lib.current_stream())
+
+
 # --------------------------------------------------------------- bf16x3: float32-accurate MFMA kernels
 def _split(x):
     hi = x.to(torch.bfloat16)
