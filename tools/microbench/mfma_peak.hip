@@ -268,6 +268,52 @@ __global__ __launch_bounds__(512, 2) void loop32(const bf16x8* __restrict__ src,
   out[blockIdx.x * 512 + tid] = s;
 }
 
+// the two-image k-step on 32x32x16 MFMAs: 32 channels x 288 pixels per wavefront as 9 accumulator tiles of
+// 32 x 32; per 32 input channels the same 18 LDS reads and 2 weight loads, but 18 MFMA instructions instead of 36
+__global__ __launch_bounds__(512, 2) void loop32w(const bf16x8* __restrict__ src, const void* wts, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 9 * 1024 * 8 / 16; i += blockDim.x) *reinterpret_cast<bf16x8*>(lds + i * 16) = src[i & 4095];
+  __syncthreads();
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wts), 0, 74 * 16384, 0x00020000);
+  const int wl = wave * 2048 + lane * 16;
+  auto wf = [&](int off, int nt) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wl + nt * 1024, off, 0)); };
+  constexpr int M = 9;
+  bf16x8 a[M], wq[2][2];
+  for (int i = 0; i < M; ++i) a[i] = *reinterpret_cast<const bf16x8*>(lds + lane * 16 + i * 1024);
+  for (int p = 0; p < 2; ++p) for (int n = 0; n < 2; ++n) wq[p][n] = wf(p * 16384, n);
+  f32x16 acc[M];
+  for (int m = 0; m < M; ++m) for (int j = 0; j < 16; ++j) acc[m][j] = 0;
+  const int off = lane * 16;
+  for (int it = 0; it < iters; it += 8) {
+    int wo = 2 * 16384 + (it % 64) * 16384;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      bf16x8 w2[2];
+      for (int n = 0; n < 2; ++n) w2[n] = wf(wo, n);
+      wo += 16384;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)   // the two 16-channel halves of the k-step
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0][h], a[m], acc[m], 0, 0, 0);
+          a[m] = *reinterpret_cast<const bf16x8*>(lds + off + m * 1024 + ((2 * k + h) & 7) * 9216);
+        }
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * M; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      for (int n = 0; n < 2; ++n) { wq[0][n] = wq[1][n]; wq[1][n] = w2[n]; }
+    }
+  }
+  float s = 0;
+  for (int m = 0; m < M; ++m) for (int j = 0; j < 16; ++j) s += acc[m][j];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
 int main(int argc, char** argv) {
   const double target_ms = argc > 1 ? atof(argv[1]) : 300.0;
   const int threads = argc > 2 ? atoi(argv[2]) : 512;  // 512: two wavefronts per SIMD, 256: one
@@ -282,6 +328,7 @@ int main(int argc, char** argv) {
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16w<9>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16w<18>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16y), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop32w), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16z), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16x<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop16x<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 1024 * 8));
@@ -294,9 +341,9 @@ int main(int argc, char** argv) {
     for (auto& v : h) v = zero ? 0 : (unsigned short)(0x3c00 + (rand() & 0x83ff));  // |x| in [0.5, 2) with random sign / mantissa
     CHECK(hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     for (int i = 0; i < 74 * 16384; i += 4096 * 16) CHECK(hipMemcpy((char*)wts + i, h.data(), 74 * 16384 - i < 4096 * 16 ? 74 * 16384 - i : 4096 * 16, hipMemcpyHostToDevice));
-    for (int variant = 0; variant < 9; ++variant) {
+    for (int variant = 0; variant < 10; ++variant) {
       if (variant >= 4 && threads != 512) continue;
-      const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : (variant == 6 ? 36.0 : variant >= 7 ? 72.0 : 18.0) * 2 * 16 * 16 * 32;  // per wave
+      const double flop_per_iter = variant == 2 ? 16.0 * 2 * 32 * 32 * 16 : (variant == 6 || variant == 9 ? 36.0 : variant >= 7 ? 72.0 : 18.0) * 2 * 16 * 16 * 32;  // per wave
       auto launch = [&](int iters) {
         if (variant == 0) hipLaunchKernelGGL(loop16<false>, dim3(cus), dim3(threads), 0, 0, src, out, iters);
         if (variant == 1) hipLaunchKernelGGL(loop16<true>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, out, iters);
@@ -306,6 +353,7 @@ int main(int argc, char** argv) {
         if (variant == 7) hipLaunchKernelGGL(loop16y, dim3(cus), dim3(256), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 8) hipLaunchKernelGGL(loop16z, dim3(cus), dim3(256), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 6) hipLaunchKernelGGL(loop16w<18>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
+        if (variant == 9) hipLaunchKernelGGL(loop32w, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
         if (variant == 3) hipLaunchKernelGGL(loop16w<9>, dim3(cus), dim3(threads), 9 * 1024 * 8, 0, src, wts, out, iters & ~7);
       };
       int iters = 20000;
@@ -320,13 +368,14 @@ int main(int argc, char** argv) {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (rep == 0) iters = (int)(iters * target_ms / ms);
       }
-      const double tf = flop_per_iter * iters * (variant >= 7 ? 4.0 : threads / 64.0) * cus / (ms * 1e-3) / 1e12;
-      const char* names[9] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
+      const double tf = flop_per_iter * iters * (variant == 7 || variant == 8 ? 4.0 : threads / 64.0) * cus / (ms * 1e-3) / 1e12;
+      const char* names[10] = {"16x16x32 bf16, register operands", "16x16x32 bf16 + 1 ds_read_b128 per 2 MFMAs", "32x32x16 bf16, register operands",
                               "16x16x32 + LDS reads + 2 weight loads per 18",
                               "  64 channels per wave, tiles split 5 / 4", "  64 channels per wave, tiles split 6 / 3",
                               "  two images per pass: 18 tiles per 2 weight loads",
                               "  two images, 64 channels, one wave per SIMD",
-                              "  the same, accumulators pinned in AGPRs (asm)"};
+                              "  the same, accumulators pinned in AGPRs (asm)",
+                              "  two images per pass on 32x32x16 MFMAs"};
       printf("%-46s %-6s data: %7.1f TFLOP/s  (%.1f ms, %d CUs x %d waves)\n", names[variant], zero ? "zero" : "random", tf, ms, cus, threads / 64);
     }
   }
