@@ -320,8 +320,8 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
  * and 16-pixel tile of x, frame slot s as one run of 17 pixels x 3 values + 5 values of padding: the last pixel
  * of the tile to the left (zero for a row's first tile) followed by the tile's 16 pixels.  This call writes
  * frames uint8 [B][H*W][3], normalised by /255, into slot `slot` (all D slots when fill_all != 0, or for the
- * games flagged in the optional fill_mask int32 [B]: the reset rule, train.py:49-50).  The buffer must have
- * been zero-filled once (the first tile's halo and the padding are never written).  W must be a multiple of 16.
+ * games flagged in the optional fill_mask int32 [B]: the reset rule, train.py:49-50), whole runs at a time
+ * (halo and zero padding included).  W must be a multiple of 16; frames and obs 16-byte aligned.
  * With `newest` the last slot written, slot s holds what CustomFrameStack's output (train.py:62-63) has at
  * channels 3*((s - newest - 1) mod D) + {0,1,2}; a consumer (mz_conv3x3_bf16_rot) reads it through
  * input-channel weights permuted the same way. */

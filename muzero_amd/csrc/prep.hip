@@ -120,45 +120,46 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
 // patch needs exactly these 17 columns, so its input window is D whole runs per row and no pixel has to be
 // fetched from a neighbouring tile.  A new frame costs 3 (+ 3/16) values per pixel instead of rebuilding the
 // stack (the consumer gathers a pixel's 3*D values from the D runs of its tile and undoes the rotation by
-// permuting its input-channel weights).  One thread per pixel; fill_all writes the frame into every slot
-// (the reset rule, train.py:49-50).  Halo of the first tile and padding are never written: the caller
-// provides the buffer zero-filled.
+// permuting its input-channel weights).  fill_all writes the frame into every slot (the reset rule,
+// train.py:49-50).
+// One thread per 16 bytes of a run (7 threads per (row, tile) in bf16, 14 in float32): it converts the 8 (4)
+// values of its unit - halo pixel, tile pixels or zero padding - and writes them with one 16-byte store, so
+// the lanes of a wavefront cover whole runs with consecutive addresses.
 constexpr int kRotRun = 56;
 template <typename OutT>
 __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
                                                             OutT* __restrict__ obs, int D, int HW, int W, int slot,
                                                             int fill_all, const int* __restrict__ fill_mask) {
+  constexpr int V = 16 / sizeof(OutT);      // values per 16-byte unit
+  constexpr int UPR = kRotRun / V;          // units per run
   const int b = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;  // pixel index y*W + x; W is a multiple of 16
-  if (p >= HW) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = i / UPR, u = i - t * UPR;   // tile index (y, x/16) in memory order; unit within the run
+  if (t >= HW / 16) return;
   if (fill_mask && fill_mask[b]) fill_all = 1;  // this game starts a new episode
-  const unsigned char* f = frames + ((long)b * HW + p) * 3;
-  OutT v[3];
+  const unsigned char* f = frames + ((long)b * HW + (long)t * 16) * 3 - 3;  // byte e of the run's 51 values
+  const bool first_in_row = (t % (W / 16)) == 0;
+  OutT v[V];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const float x = (float)f[r] / 255.0f;
-    if constexpr (sizeof(OutT) == 2) v[r] = f32_to_bf16_rne(x);
-    else v[r] = x;
+  for (int j = 0; j < V; ++j) {
+    const int e = u * V + j;
+    float x = 0.f;
+    if (e < 51 && !(first_in_row && e < 3)) x = (float)f[e] / 255.0f;
+    if constexpr (sizeof(OutT) == 2) v[j] = f32_to_bf16_rne(x);
+    else v[j] = x;
   }
-  // (y, x/16) = p / 16 enumerates the tiles in memory order; the pixel is element px + 1 of its own tile's
-  // run and, when it is its tile's last, element 0 of the next tile's (same row)
-  const int px = p % 16;
-  OutT* o = obs + (((long)b * (HW / 16) + p / 16) * D) * kRotRun + (px + 1) * 3;
-  const bool also_halo = px == 15 && (p % W) != W - 1;
-  const long halo = (long)D * kRotRun - 16 * 3;  // from own element to element 0 of the next tile's run
-  if (fill_all) {
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        o[d * kRotRun + r] = v[r];
-        if (also_halo) o[d * kRotRun + halo + r] = v[r];
-      }
+  uint4 pk;
+  if constexpr (sizeof(OutT) == 2) {
+    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2] | ((unsigned)v[3] << 16);
+    pk.z = v[4] | ((unsigned)v[5] << 16); pk.w = v[6] | ((unsigned)v[7] << 16);
   } else {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      o[slot * kRotRun + r] = v[r];
-      if (also_halo) o[slot * kRotRun + halo + r] = v[r];
-    }
+    pk.x = __float_as_uint(v[0]); pk.y = __float_as_uint(v[1]); pk.z = __float_as_uint(v[2]); pk.w = __float_as_uint(v[3]);
+  }
+  OutT* o = obs + (((long)b * (HW / 16) + t) * D) * kRotRun + u * V;
+  if (fill_all) {
+    for (int d = 0; d < D; ++d) *reinterpret_cast<uint4*>(o + d * kRotRun) = pk;
+  } else {
+    *reinterpret_cast<uint4*>(o + slot * kRotRun) = pk;
   }
 }
 
@@ -252,7 +253,9 @@ int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int
   MZ_REQUIRE(W % 16 == 0, "mz_obs_slot_write: the image width must be a multiple of 16 (W = %d)", W);
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
   const int HW = H * W;
-  const dim3 grid((HW + 255) / 256, B);
+  MZ_REQUIRE((uintptr_t)obs % 16 == 0, "mz_obs_slot_write: obs must be 16-byte aligned");
+  const int units = (HW / 16) * (out_is_bf16 ? 7 : 14);   // 16-byte units of one slot's runs per game
+  const dim3 grid((units + 255) / 256, B);
   if (out_is_bf16)
     hipLaunchKernelGGL(obs_slot_write_kernel<unsigned short>, grid, dim3(256), 0, mz::as_stream(stream), frames,
                        static_cast<unsigned short*>(obs), D, HW, W, slot, fill_all, fill_mask);
