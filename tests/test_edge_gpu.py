@@ -215,7 +215,8 @@ def test_rotating_observation_equals_the_stacked_one():
         assert d <= 0.02 * h_true.float().abs().max().item()
 
 
-def test_per_game_restart_refills_only_the_flagged_stacks():
+@pytest.mark.parametrize("rot_dtype", [torch.bfloat16, torch.float32])
+def test_per_game_restart_refills_only_the_flagged_stacks(rot_dtype):
     """push(frames, restarted): flagged games get the reset rule (every slot = the new frame), the
     others an ordinary push; both the u8 ring's stacked observation and the rotating one agree
     with a host model of 5 independent frame stacks."""
@@ -223,7 +224,7 @@ def test_per_game_restart_refills_only_the_flagged_stacks():
     rng = np.random.default_rng(9)
     B, D = 5, 32
     ring = FrameRing(B, D, 96, 96)
-    ring.enable_rotating(torch.bfloat16)
+    ring.enable_rotating(rot_dtype)
     new = lambda: rng.integers(0, 256, (B, 96, 96, 3), dtype=np.uint8)
     f = new()
     ring.reset(torch.from_numpy(f))
@@ -239,7 +240,8 @@ def test_per_game_restart_refills_only_the_flagged_stacks():
     assert np.array_equal(got, (want.astype(np.float32) / np.float32(255.0)))
     rot, newest = ring.rotating_observation()
     perm = ring.rotation_permutation().cuda()
-    assert torch.equal(ring.observation(torch.bfloat16)[..., perm], untile(rot))
+    assert rot.dtype == rot_dtype
+    assert torch.equal(ring.observation(rot_dtype)[..., perm], untile(rot))
     _check_rot_halo(rot)
 
 
