@@ -90,7 +90,7 @@ class _Conv3x3Native(torch.autograd.Function):
         n = x.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            zero = torch.zeros(256, dtype=torch.float32, device=x.device)
+            zero = _zero_bias(x.device)
             dx = _Conv3x3Native._conv(gh, ctx.packed.get(weight, True), zero).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1] and ctx.packed.pending is not None:
             ctx.packed.pending.append((gh, xh))       # summed over the unroll steps by Conv3x3.flush_wgrad
@@ -108,6 +108,17 @@ class _Conv3x3Native(torch.autograd.Function):
 
 
 _WGRAD_WS: Dict[tuple, torch.Tensor] = {}
+_ZERO_BIAS: Dict[tuple, torch.Tensor] = {}
+
+
+def _zero_bias(device) -> torch.Tensor:
+    """The all-zero bias of a data-gradient convolution (one per device, never written)."""
+    key = (device.type, device.index)
+    t = _ZERO_BIAS.get(key)
+    if t is None:
+        t = _ZERO_BIAS[key] = torch.zeros(256, dtype=torch.float32, device=device)
+    return t
+
 
 
 def _wgrad_workspace(nbytes: int, device) -> torch.Tensor:
@@ -215,6 +226,26 @@ class _BNActNative(torch.autograd.Function):
         return dx, dres, dgamma, dbeta, None, None, None, None
 
 
+_BN_COUNTS: Optional[dict] = None
+
+
+class count_bn_applications:
+    """Context manager around a forward pass: the fused BatchNorm path's ``num_batches_tracked += 1`` of every
+    application (one tiny launch each, ~50 per unrolled update) becomes one multi-tensor add at the end."""
+
+    def __enter__(self):
+        global _BN_COUNTS
+        self._outer, _BN_COUNTS = _BN_COUNTS, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_COUNTS
+        counts, _BN_COUNTS = _BN_COUNTS, self._outer
+        if counts and exc[0] is None:
+            torch._foreach_add_([bn.num_batches_tracked for bn in counts], [int(n) for n in counts.values()])
+        return False
+
+
 def bn_act(bn: nn.BatchNorm2d, x, residual=None):
     """relu(bn(x) [+ residual]) (model.py:155-158, :166, :237).  The fused kernels serve training-mode BatchNorm on
     bf16 channels_last activations - what the native convolutions produce - when the learner computes in bf16;
@@ -225,7 +256,10 @@ def bn_act(bn: nn.BatchNorm2d, x, residual=None):
         with torch.autocast("cuda", enabled=False):
             if residual is not None:
                 residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            bn.num_batches_tracked.add_(1)
+            if _BN_COUNTS is not None:          # counted once per pass by count_bn_applications
+                _BN_COUNTS[bn] = _BN_COUNTS.get(bn, 0) + 1
+            else:
+                bn.num_batches_tracked.add_(1)
             return _BNActNative.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                       bn.momentum)
     y = bn(x)
@@ -874,7 +908,7 @@ class Learner:
         reward_logits = None
         total_v = total_r = total_p = 0.0
         per_sample = 0.0
-        with amp:
+        with amp, count_bn_applications():
             hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
             for t in range(K + 1):
                 with f32_math:
