@@ -338,13 +338,18 @@ class _Dynamics(nn.Module):
         self.resblocks = nn.ModuleList([_Res(width) for _ in range(n_blocks)])
         self.reward_head = _mlp(width, fc_reward, 2 * support + 1)
 
-    def forward(self, h, action):
+    def trunk(self, h, action):
+        """The next hidden state (model.py:231-241 without the reward head)."""
         # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
         w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
         x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
         x = bn_act(self.bn, self.conv_state(x))
         for b in self.resblocks:
             x = b(x)
+        return x
+
+    def forward(self, h, action):
+        x = self.trunk(h, action)
         return x, self.reward_head(x.mean(dim=(2, 3)))
 
 
@@ -379,6 +384,22 @@ class TrainableNetwork(nn.Module):
         h2, r = self.dynamics(h, action)
         p, v = self.prediction(h2)
         return h2, r, p, v
+
+    def unroll(self, obs, actions):
+        """initial + K x recurrent (train.py:343-372) with the heads applied ONCE to the hidden states of all
+        K + 1 steps: the heads are per-sample MLPs on the spatial mean, so (K + 1) x B rows through each head
+        equal K + 1 applications to B rows - one sixth of the small GEMMs, bias / ReLU kernels and
+        gradient-accumulation adds of an update.  actions: int64 [B, K].  Returns the policy and value logits
+        [(K+1) B, .] (step-major: rows t B .. (t+1) B - 1 are step t) and the reward logits [K B, .] (steps 1..K)."""
+        h = self.representation(obs)
+        means = [h.mean(dim=(2, 3))]
+        for t in range(actions.shape[1]):
+            h = self.dynamics.trunk(h, actions[:, t])
+            means.append(h.mean(dim=(2, 3)))
+        m = torch.cat(means)
+        policy, value = self.prediction.policy_head(m), self.prediction.value_head(m)
+        reward = self.dynamics.reward_head(m[means[0].shape[0]:]) if len(means) > 1 else None
+        return policy, value, reward
 
 
 # --------------------------------------------------------------------------- loss
@@ -905,30 +926,23 @@ class Learner:
         # update, not once per unroll step); the losses are computed in float32 with autocast switched off
         amp = torch.autocast(dev.type, dtype=torch.bfloat16, enabled=self.precision == "bf16")
         f32_math = torch.autocast(dev.type, enabled=False)
-        reward_logits = None
-        total_v = total_r = total_p = 0.0
-        per_sample = 0.0
+        B = tv.shape[0]
         with amp, count_bn_applications():
-            hidden, policy_logits, value_logits = self.network.initial(observations.to(dev))
-            for t in range(K + 1):
-                with f32_math:
-                    policy_logits, value_logits = policy_logits.float(), value_logits.float()
-                    v_loss = support_ce_loss(value_logits, tv[:, t], S, self.loss_impl)
-                    p_loss = -(tp[:, t] * torch.log_softmax(policy_logits, dim=1)).sum(1)
-                    r_loss = support_ce_loss(reward_logits.float(), tr[:, t], S, self.loss_impl) if t > 0 \
-                        else torch.zeros(tv.shape[0], device=dev)
-                    total = cfg.value_loss_weight * v_loss + cfg.reward_loss_weight * r_loss \
-                        + cfg.policy_loss_weight * p_loss
-                    per_sample = per_sample + total * w
-                    total_v = total_v + v_loss.mean()
-                    total_r = total_r + r_loss.mean()
-                    total_p = total_p + p_loss.mean()
-                if t < K:
-                    hidden, reward_logits, policy_logits, value_logits = self.network.recurrent(hidden, act[:, t])
-        total_v = total_v / (K + 1)
-        total_p = total_p / (K + 1)
-        total_r = total_r / K if K > 0 else torch.zeros(1, device=dev)
-        return total_v, total_r, total_p, per_sample / (K + 1)
+            policy_logits, value_logits, reward_logits = self.network.unroll(observations.to(dev), act[:, :K])
+        with f32_math:
+            # every step's loss in one go; row t B + b of the logits is step t of sample b
+            step_major = lambda x: x.transpose(0, 1).reshape(x.shape[1] * B, *x.shape[2:])
+            v_loss = support_ce_loss(value_logits.float(), step_major(tv), S, self.loss_impl).view(K + 1, B)
+            p_loss = -(step_major(tp) * torch.log_softmax(policy_logits.float(), dim=1)).sum(1).view(K + 1, B)
+            r_loss = torch.zeros(1, B, device=dev)                   # no reward prediction at the root
+            if K > 0:
+                r_loss = torch.cat([r_loss, support_ce_loss(reward_logits.float(), step_major(tr[:, 1:]), S,
+                                                            self.loss_impl).view(K, B)])
+            total = cfg.value_loss_weight * v_loss + cfg.reward_loss_weight * r_loss + cfg.policy_loss_weight * p_loss
+            per_sample = (total * w).sum(0) / (K + 1)
+            total_v, total_p = v_loss.mean(), p_loss.mean()
+            total_r = r_loss[1:].mean() if K > 0 else torch.zeros(1, device=dev)
+        return total_v, total_r, total_p, per_sample
 
     def update_weights(self, batch, weights):
         """One optimisation step (train.py:303-313).  Returns the metrics and the per-sample
