@@ -366,6 +366,14 @@ int mz_weights_fold_pack(const float* w, const float* conv_bias, const float* bn
                          int32_t cin_chunk, int32_t mode, int32_t transpose, int32_t rot_depth, void* out,
                          float* bias_out, mz_stream_t stream);
 
+/* mz_weights_fold_pack(mode 0, no BatchNorm, no rotation) for n weights of one shape in a single launch: w[i]
+ * float [Cout][Cin][3][3] -> out[i] (mz_packed_conv_elems(Cout, Cin, 0) bf16 elements), in the transposed,
+ * mirrored data-gradient form where transpose[i] != 0 (transpose may be null).  w, out, transpose: HOST arrays
+ * of n entries (device pointers inside).  The unrolled training step (train.py:303-313) changes every weight
+ * once per update; its native convolutions need both forms of all of them again. */
+int mz_weights_pack_many(const float* const* w, void* const* out, const int32_t* transpose, int32_t n, int32_t Cout,
+                         int32_t Cin, int32_t cin_chunk, mz_stream_t stream);
+
 /* A torch Linear layer (weight [O][K], bias [O]) in the fragment order of mz_head_weights (float32, or bf16 when
  * bf16 != 0) with the bias zero-padded to a multiple of 16. */
 int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int32_t bf16, void* w_packed,

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "mz_packed_conv_elems": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "mz_weights_fold_pack": (C.c_int, [_P] * 6 + [C.c_double] + [C.c_int32] * 6 + [_P, _P, _P]),
     "mz_pack_linear": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mz_weights_pack_many": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mz_action_vectors": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "mz_comm_unique_id": (C.c_int, [_P]),
     "mz_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -50,10 +50,43 @@ __device__ __forceinline__ float folded_weight(const PackArgs& a, int co, int ci
   return raw;
 }
 
+// bf16 fragments of copy `copy`: thread `unit` writes 8 consecutive packed elements (or zeros of the padding)
+__device__ __forceinline__ void pack_fragments(const PackArgs& a, int copy, long unit) {
+  const int NT = a.Cout / 16, KC = a.chunk / 32;
+  const long per_copy = (long)a.Cout * a.Cin * 9;
+  const long units = per_copy / 8;
+  __bf16* out = reinterpret_cast<__bf16*>(a.out) + copy * a.copy_elems;
+  if (unit >= units) {  // the two k-steps of zeros behind the fragments (prefetch overrun)
+    const long z = unit - units;
+    if (z < 2L * NT * 64) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      *reinterpret_cast<bf16x8*>(out + per_copy + z * 8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    return;
+  }
+  // unit = (((cc*9 + tap)*KC + kc)*NT + nt)*64 + lane
+  const int lane = (int)(unit & 63);
+  long r = unit >> 6;
+  const int nt = (int)(r % NT); r /= NT;
+  const int kc = (int)(r % KC); r /= KC;
+  const int tap = (int)(r % 9);
+  const int cc = (int)(r / 9);
+  const int co = nt * 16 + (lane & 15);
+  const int cbase = cc * a.chunk + kc * 32 + 8 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int cj = cbase + j;
+    int ci = cj;
+    if (a.rot_depth > 0) ci = ((cj / 3 - copy - 1 + 2 * a.rot_depth) % a.rot_depth) * 3 + cj % 3;
+    const float f = folded_weight(a, co, ci, tap);
+    const __bf16 hi = (__bf16)f;
+    out[unit * 8 + j] = a.mode == 0 ? hi : (__bf16)(f - (float)hi);
+  }
+}
+
 // one thread per 8 consecutive packed elements (bf16 modes) or per element (float32 mode)
 __global__ void pack_conv_kernel(PackArgs a) {
   const int copy = blockIdx.y;
-  const int NT = a.Cout / 16, KC = a.chunk / 32;
   const long per_copy = (long)a.Cout * a.Cin * 9;
   if (a.mode == 2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -65,35 +98,7 @@ __global__ void pack_conv_kernel(PackArgs a) {
     if (a.rot_depth > 0) ci = ((cj / 3 - copy - 1 + 2 * a.rot_depth) % a.rot_depth) * 3 + cj % 3;
     reinterpret_cast<float*>(a.out)[copy * a.copy_elems + i] = folded_weight(a, co, ci, tap);
   } else {
-    const long unit = (long)blockIdx.x * blockDim.x + threadIdx.x;  // index of a (.., lane) group of 8
-    const long units = per_copy / 8;
-    __bf16* out = reinterpret_cast<__bf16*>(a.out) + copy * a.copy_elems;
-    if (unit >= units) {  // the two k-steps of zeros behind the fragments (prefetch overrun)
-      const long z = unit - units;
-      if (z < 2L * NT * 64) {
-        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-        *reinterpret_cast<bf16x8*>(out + per_copy + z * 8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      }
-      return;
-    }
-    // unit = (((cc*9 + tap)*KC + kc)*NT + nt)*64 + lane
-    const int lane = (int)(unit & 63);
-    long r = unit >> 6;
-    const int nt = (int)(r % NT); r /= NT;
-    const int kc = (int)(r % KC); r /= KC;
-    const int tap = (int)(r % 9);
-    const int cc = (int)(r / 9);
-    const int co = nt * 16 + (lane & 15);
-    const int cbase = cc * a.chunk + kc * 32 + 8 * (lane >> 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int cj = cbase + j;
-      int ci = cj;
-      if (a.rot_depth > 0) ci = ((cj / 3 - copy - 1 + 2 * a.rot_depth) % a.rot_depth) * 3 + cj % 3;
-      const float f = folded_weight(a, co, ci, tap);
-      const __bf16 hi = (__bf16)f;
-      out[unit * 8 + j] = a.mode == 0 ? hi : (__bf16)(f - (float)hi);
-    }
+    pack_fragments(a, copy, (long)blockIdx.x * blockDim.x + threadIdx.x);
   }
   if (a.bias_out && copy == 0 && blockIdx.x == 0) {
     for (int c = threadIdx.x; c < a.Cout; c += blockDim.x) {
@@ -105,6 +110,26 @@ __global__ void pack_conv_kernel(PackArgs a) {
       a.bias_out[c] = b;
     }
   }
+}
+
+// Several weights of one shape in one launch (plain bf16 fragments, optionally the transposed form): the
+// training step repacks every native layer twice per update, and a launch each is all overhead
+constexpr int kMaxPackMany = 64;
+struct PackMany {
+  const float* w[kMaxPackMany];
+  void* out[kMaxPackMany];
+  unsigned long long transposed;  // bit i: item i in the data-gradient form
+  int Cout, Cin, chunk;
+};
+
+__global__ void pack_many_kernel(PackMany m) {
+  const int item = blockIdx.y;
+  PackArgs a{};
+  a.w = m.w[item];
+  a.Cout = m.Cout, a.Cin = m.Cin, a.chunk = m.chunk;
+  a.transpose = (int)((m.transposed >> item) & 1ull);
+  a.out = m.out[item];
+  pack_fragments(a, 0, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // torch Linear weight [O][K] -> MFMA fragments, rows beyond O zero (cf. mz_heads)
@@ -173,6 +198,30 @@ int mz_weights_fold_pack(const float* w, const float* conv_bias, const float* bn
   hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((threads + 255) / 256), rot_depth > 0 ? rot_depth : 1), dim3(256),
                      0, mz::as_stream(stream), a);
   return mz::check_launch("mz_weights_fold_pack");
+}
+
+int mz_weights_pack_many(const float* const* w, void* const* out, const int32_t* transpose, int32_t n, int32_t Cout,
+                         int32_t Cin, int32_t cin_chunk, mz_stream_t stream) {
+  MZ_REQUIRE(w && out && n > 0 && Cout > 0 && Cin > 0, "mz_weights_pack_many: null table or empty shape");
+  MZ_REQUIRE(Cout % 16 == 0 && cin_chunk > 0 && cin_chunk % 32 == 0 && Cin % cin_chunk == 0,
+             "mz_weights_pack_many: fragments need Cout %% 16 == 0 and Cin a multiple of the chunk (%d, %d, %d)", Cout, Cin,
+             cin_chunk);
+  const long n_el = (long)Cout * Cin * 9;
+  const long threads = n_el / 8 + 2L * (Cout / 16) * 64;
+  for (int i0 = 0; i0 < n; i0 += kMaxPackMany) {
+    const int cnt = n - i0 < kMaxPackMany ? n - i0 : kMaxPackMany;
+    PackMany m{};
+    m.Cout = Cout, m.Cin = Cin, m.chunk = cin_chunk;
+    for (int i = 0; i < cnt; ++i) {
+      MZ_REQUIRE(w[i0 + i] && out[i0 + i], "mz_weights_pack_many: item %d has a null pointer", i0 + i);
+      MZ_REQUIRE(!(transpose && transpose[i0 + i]) || Cin == Cout, "mz_weights_pack_many: the transposed form is for square layers");
+      m.w[i] = w[i0 + i];
+      m.out[i] = out[i0 + i];
+      if (transpose && transpose[i0 + i]) m.transposed |= 1ull << i;
+    }
+    hipLaunchKernelGGL(pack_many_kernel, dim3((unsigned)((threads + 255) / 256), cnt), dim3(256), 0, mz::as_stream(stream), m);
+  }
+  return mz::check_launch("mz_weights_pack_many");
 }
 
 int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int32_t bf16, void* w_packed,

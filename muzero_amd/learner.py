@@ -42,21 +42,35 @@ class _PackedWeights:
         self._slots = {}
         self.pending = None      # a list while the layer's weight gradients are deferred (see Conv3x3.defer_wgrad)
 
-    def get(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
-        from . import mfma
+    def key(self, weight: torch.Tensor):
         # while a HIP graph of the update is being recorded the packing must be part of it (a replay runs no
-        # Python, so the version check cannot happen then): pack at the first use in every forward / backward
-        # pass, into the existing buffer - a layer applied at several unroll steps packs once per pass
+        # Python, so the version check cannot happen then): pack in every forward / backward pass
         epoch = _PACK_EPOCH[0] if torch.cuda.is_current_stream_capturing() else -1
-        key = (weight.data_ptr(), weight._version, epoch)
+        return (weight.data_ptr(), weight._version, epoch)
+
+    def buffer(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+        """The (possibly stale) packed buffer of one form, allocated on first use."""
+        from . import mfma
+        slot = self._slots.get(transpose)
+        if slot is None:
+            slot = self._slots[transpose] = (None, torch.empty(mfma.packed_elems(256, 256), dtype=torch.bfloat16,
+                                                               device=weight.device))
+        return slot[1]
+
+    def mark_current(self, weight: torch.Tensor, transpose: bool) -> None:
+        self._slots[transpose] = (self.key(weight), self._slots[transpose][1])
+
+    def get(self, weight: torch.Tensor, transpose: bool) -> torch.Tensor:
+        """The packed form, repacked first if the weight has changed (a layer applied at several unroll steps
+        packs once per pass; Learner packs all layers at the start of a pass in one launch)."""
+        key = self.key(weight)
         slot = self._slots.get(transpose)
         if slot is None or slot[0] != key:
-            buf = slot[1] if slot is not None else torch.empty(mfma.packed_elems(256, 256), dtype=torch.bfloat16,
-                                                               device=weight.device)
+            buf = self.buffer(weight, transpose)
             _lib.call("mz_weights_fold_pack", _lib.ptr(weight.detach()), None, None, None, None, None, 0.0, 256, 256, 256,
                       0, 1 if transpose else 0, 0, _lib.ptr(buf), None, _lib.current_stream())
-            slot = self._slots[transpose] = (key, buf)
-        return slot[1]
+            self._slots[transpose] = (key, buf)
+        return self._slots[transpose][1]
 
 
 class _Conv3x3Native(torch.autograd.Function):
@@ -919,6 +933,7 @@ class Learner:
         K, S = cfg.num_unroll_steps, cfg.support_size
         dev = self.device
         _PACK_EPOCH[0] += 1
+        self._pack_native_weights()
         f32 = lambda x: torch.as_tensor(x, device=dev).float()
         tv, tr, tp, w = f32(target_values), f32(target_rewards), f32(target_policies), f32(weights)
         act = torch.as_tensor(actions, device=dev).long()
@@ -1007,6 +1022,27 @@ class Learner:
         m = m.cpu().numpy()
         return {"value_loss": float(m[0]), "reward_loss": float(m[1]), "policy_loss": float(m[2]),
                 "total_loss": float(m[3]), "priorities": per.cpu().numpy()}
+
+    def _pack_native_weights(self) -> None:
+        """Both packed forms (forward, data gradient) of every native convolution whose weight has changed since
+        it was last packed, in ONE launch (mz_weights_pack_many) instead of one per layer and form at first use."""
+        if not self.native_convs:
+            return
+        convs = getattr(self, "_native_conv_list", None)
+        if convs is None:
+            convs = self._native_conv_list = [m for m in self.network.modules() if isinstance(m, Conv3x3)
+                                              and m.stride == (1, 1) and tuple(m.weight.shape) == (256, 256, 3, 3)]
+        todo = [(m, t) for m in convs for t in (False, True)
+                if m._packed._slots.get(t) is None or m._packed._slots[t][0] != m._packed.key(m.weight)]
+        if not todo:
+            return
+        n = len(todo)
+        w = (C.c_void_p * n)(*[m.weight.data_ptr() for m, _ in todo])
+        out = (C.c_void_p * n)(*[m._packed.buffer(m.weight, t).data_ptr() for m, t in todo])
+        tr = (C.c_int32 * n)(*[1 if t else 0 for _, t in todo])
+        _lib.call("mz_weights_pack_many", w, out, tr, n, 256, 256, 256, _lib.current_stream())
+        for m, t in todo:
+            m._packed.mark_current(m.weight, t)
 
     def _backward(self, loss) -> None:
         """loss.backward() with the weight gradients of the dynamics network's native convolutions - applied

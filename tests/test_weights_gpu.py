@@ -128,3 +128,30 @@ def test_rccl_weight_broadcast_entry_points_single_rank():
     with pytest.raises(Exception):
         comm.broadcast(flat, 3)              # root outside the communicator
     comm.close()
+
+
+def test_pack_many_equals_single_packs():
+    """mz_weights_pack_many (several weights of one shape, forward and data-gradient forms, one launch) writes
+    exactly what mz_weights_fold_pack writes for each of them."""
+    import ctypes as C
+    from muzero_amd import _lib, mfma
+    g = torch.Generator().manual_seed(3)
+    n = 5
+    ws = [(torch.randn(256, 256, 3, 3, generator=g) / 48.0).cuda() for _ in range(n)]
+    forms = [0, 1, 1, 0, 1]
+    elems = mfma.packed_elems(256, 256)
+    many = [torch.full((elems,), 7.0, dtype=torch.bfloat16, device="cuda") for _ in range(n)]
+    single = [torch.full((elems,), 9.0, dtype=torch.bfloat16, device="cuda") for _ in range(n)]
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    op = (C.c_void_p * n)(*[o.data_ptr() for o in many])
+    tr = (C.c_int32 * n)(*forms)
+    _lib.call("mz_weights_pack_many", wp, op, tr, n, 256, 256, 256, _lib.current_stream())
+    for w, o, t in zip(ws, single, forms):
+        _lib.call("mz_weights_fold_pack", _lib.ptr(w), None, None, None, None, None, 0.0, 256, 256, 256, 0, t, 0,
+                  _lib.ptr(o), None, _lib.current_stream())
+    torch.cuda.synchronize()
+    for a, b in zip(many, single):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    with pytest.raises(_lib.MuZeroAmdError, match="null"):
+        bad = (C.c_void_p * n)(*([w.data_ptr() for w in ws[:-1]] + [None]))
+        _lib.call("mz_weights_pack_many", bad, op, tr, n, 256, 256, 256, _lib.current_stream())
