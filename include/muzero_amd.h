@@ -451,6 +451,20 @@ int mz_bn_relu_train_fwd(const void* x, const void* residual, const float* gamma
                          float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
                          int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd, void* workspace,
                          int64_t workspace_bytes, mz_stream_t stream);
+/* The same with the column sums supplied by the producer of x instead of a pass over x: stats double
+ * [stat_blocks][2][C] = partial sums of x and of x * x (any split of the rows), e.g. per image from
+ * mz_conv3x3_bf16_stats. */
+int mz_bn_relu_train_fwd_stats(const void* x, const void* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
+                               int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd,
+                               const double* stats, int32_t stat_blocks, void* workspace, int64_t workspace_bytes,
+                               mz_stream_t stream);
+/* mz_conv3x3_bf16 for the 12x12, 256 -> 256, stride-1 layer without residual or ReLU (a convolution in front of
+ * a training-mode BatchNorm, model.py:152-157 under train.py:343 / :411) that also writes, per image, the sums
+ * the BatchNorm needs: stats double [B][2][256] = sum and sum of squares over the image's 144 pixels of the
+ * bf16-rounded outputs. */
+int mz_conv3x3_bf16_stats(const void* in, const void* wpk, const float* bias, void* out, double* stats, int32_t B,
+                          mz_stream_t stream);
 int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
                          const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx, void* dresidual,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mz_stream_t stream);

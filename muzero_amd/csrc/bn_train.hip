@@ -247,30 +247,53 @@ extern "C" {
 
 int64_t mz_bn_workspace_bytes(int32_t C) { return C > 0 ? (int64_t)kMaxStatBlocks * 2 * C * 8 + 3 * (int64_t)C * 4 : 0; }
 
-int mz_bn_relu_train_fwd(const void* x, const void* residual, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
-                         int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd, void* workspace,
-                         int64_t workspace_bytes, mz_stream_t stream) {
-  MZ_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "mz_bn_relu_train_fwd: null argument");
-  MZ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "mz_bn_relu_train_fwd: running statistics go together");
-  if (int rc = check_shape("mz_bn_relu_train_fwd", rows, C)) return rc;
-  MZ_REQUIRE(workspace_bytes >= mz_bn_workspace_bytes(C), "mz_bn_relu_train_fwd: workspace too small");
+static int bn_fwd(const char* who, const void* x, const void* residual, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, double eps, double momentum, int32_t relu, int64_t rows,
+                  int32_t C, void* y, float* save_mean, float* save_invstd, const double* stats, int32_t stat_blocks_in,
+                  void* workspace, int64_t workspace_bytes, mz_stream_t stream) {
+  MZ_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "%s: null argument", who);
+  MZ_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running statistics go together", who);
+  if (int rc = check_shape(who, rows, C)) return rc;
+  MZ_REQUIRE(workspace_bytes >= mz_bn_workspace_bytes(C), "%s: workspace too small", who);
   hipStream_t s = mz::as_stream(stream);
   double* partial = static_cast<double*>(workspace);
   float* scale = reinterpret_cast<float*>(partial + (long)kMaxStatBlocks * 2 * C);
   float* shift = scale + C;
-  const int blocks = stat_blocks(rows, C);
-  const int lanes = kStatsThreads / (C / 8);
   const auto* xs = static_cast<const unsigned short*>(x);
-  hipLaunchKernelGGL(bn_colsum_kernel<0>, dim3(blocks), dim3(kStatsThreads), (size_t)lanes * 2 * C * 8, s, xs, nullptr,
-                     nullptr, nullptr, nullptr, 0, (long)rows, C, partial);
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, partial, blocks, (long)rows, C, eps,
-                     momentum, gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  int blocks = stat_blocks_in;
+  const double* sums = stats;
+  if (!stats) {  // column sums of x per workgroup
+    blocks = stat_blocks(rows, C);
+    const int lanes = kStatsThreads / (C / 8);
+    hipLaunchKernelGGL(bn_colsum_kernel<0>, dim3(blocks), dim3(kStatsThreads), (size_t)lanes * 2 * C * 8, s, xs, nullptr,
+                       nullptr, nullptr, nullptr, 0, (long)rows, C, partial);
+    sums = partial;
+  }
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, sums, blocks, (long)rows, C, eps, momentum,
+                     gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift);
   const long units = rows * (C / 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(apply_blocks(units)), dim3(256), 0, s, xs,
                      static_cast<const unsigned short*>(residual), scale, shift, relu, units, C,
                      static_cast<unsigned short*>(y));
-  return mz::check_launch("mz_bn_relu_train_fwd");
+  return mz::check_launch(who);
+}
+
+int mz_bn_relu_train_fwd(const void* x, const void* residual, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
+                         int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd, void* workspace,
+                         int64_t workspace_bytes, mz_stream_t stream) {
+  return bn_fwd("mz_bn_relu_train_fwd", x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu, rows, C,
+                y, save_mean, save_invstd, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+int mz_bn_relu_train_fwd_stats(const void* x, const void* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, double eps, double momentum, int32_t relu,
+                               int64_t rows, int32_t C, void* y, float* save_mean, float* save_invstd,
+                               const double* stats, int32_t stat_blocks, void* workspace, int64_t workspace_bytes,
+                               mz_stream_t stream) {
+  MZ_REQUIRE(stats && stat_blocks > 0, "mz_bn_relu_train_fwd_stats: stats [stat_blocks][2][C] expected");
+  return bn_fwd("mz_bn_relu_train_fwd_stats", x, residual, gamma, beta, running_mean, running_var, eps, momentum, relu,
+                rows, C, y, save_mean, save_invstd, stats, stat_blocks, workspace, workspace_bytes, stream);
 }
 
 int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,

@@ -22,7 +22,7 @@
 namespace mz {
 int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
                     const void* residual, void* out, const float* action_vec, const int32_t* actions,
-                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream);
+                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream, double* stats = nullptr);
 int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
                     int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
                     int32_t B, hipStream_t stream);
@@ -314,6 +314,13 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<ConvDown1>(a, B, s);
   return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
                   Cout, stride);
+}
+
+int mz_conv3x3_bf16_stats(const void* in, const void* wpk, const float* bias, void* out, double* stats, int32_t B,
+                          mz_stream_t stream) {
+  MZ_REQUIRE(in && wpk && bias && out && stats && B > 0, "mz_conv3x3_bf16_stats: null tensor or empty batch");
+  return mz::conv_trunk_bf16(in, nullptr, 0, wpk, bias, nullptr, out, nullptr, nullptr, nullptr, B, 0, mz::as_stream(stream),
+                             stats);
 }
 
 int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,

@@ -32,6 +32,7 @@ struct TrunkArgs {
   const int* actions;
   float* mean_out;
   int relu;
+  double* stats;  // optional [image][2][256]: per-channel sum and sum of squares of the image's (rounded) outputs
 };
 
 template <int NW>
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
     const int cbase = (tile0 + nt) * 16 + kq * 4;
     const float4 bv = *reinterpret_cast<const float4*>(a.bias + cbase);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};  // sums of the ROUNDED outputs and of their squares
 #pragma unroll
     for (int mt = 0; mt < kMT; ++mt) {
       char* slot = ldsB + (mt * 16 + r16) * kRowB + cbase * 2;
@@ -201,7 +203,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
       }
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
       const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+      if (a.stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float r = (float)ov[j];
+          t[j] += r;
+          q[j] += r * r;
+        }
+      }
       *reinterpret_cast<bf16x4*>(slot) = ov;
+    }
+    if (a.stats) {  // what a following training-mode BatchNorm needs of this image: per lane 9 pixels, then the 16 lanes
+      double td[4], qd[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        td[j] = (double)t[j];
+        qd[j] = (double)q[j];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          td[j] += __shfl_xor(td[j], m);
+          qd[j] += __shfl_xor(qd[j], m);
+        }
+      }
+      if (r16 == 0) {
+        double* st = a.stats + (long)b * 2 * kCh + cbase;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st[j] = td[j];
+          st[kCh + j] = qd[j];
+        }
+      }
     }
     if (a.mean_out) {
 #pragma unroll
@@ -829,9 +860,10 @@ namespace mz {
 // called by mz_conv3x3_bf16 for the 12x12x256->256 stride-1 shape
 int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
                     const void* residual, void* out, const float* action_vec, const int32_t* actions,
-                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream) {
+                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream, double* stats) {
   TrunkArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
-              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
+              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu,
+              stats};
   // two workgroups per image while that still leaves CUs idle otherwise
   if (2 * B <= mz::compute_units()) return launch_trunk<8, 2, 2>(a, B, stream);
   return launch_trunk<8, 2, 1>(a, B, stream);

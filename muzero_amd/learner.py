@@ -87,17 +87,27 @@ class _Conv3x3Native(torch.autograd.Function):
         return out
 
     @staticmethod
-    def forward(ctx, x, weight, bias, packed):
+    def forward(ctx, x, weight, bias, packed, want_stats=False):
+        """want_stats: also return double [N, 2, 256], per image the sum and the sum of squares of the outputs -
+        the column sums a following training-mode BatchNorm would otherwise get from a pass of its own."""
         xh = x.permute(0, 2, 3, 1)
         if not xh.is_contiguous() or x.dtype != torch.bfloat16:
             raise ValueError("native convolution: bf16 channels_last input expected")
         ctx.save_for_backward(x, weight)
         ctx.packed = packed
-        out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float())
-        return out.permute(0, 3, 1, 2)
+        if not want_stats:
+            out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float())
+            return out.permute(0, 3, 1, 2)
+        n = xh.shape[0]
+        out = torch.empty_like(xh)
+        stats = torch.empty(n, 2, 256, dtype=torch.float64, device=x.device)
+        _lib.call("mz_conv3x3_bf16_stats", _lib.ptr(xh), _lib.ptr(packed.get(weight, False)),
+                  _lib.ptr(bias.detach().float()), _lib.ptr(out), _lib.ptr(stats), n, _lib.current_stream())
+        ctx.mark_non_differentiable(stats)
+        return out.permute(0, 3, 1, 2), stats
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, *unused):
         x, weight = ctx.saved_tensors
         g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         gh, xh = g.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1)
@@ -118,7 +128,7 @@ class _Conv3x3Native(torch.autograd.Function):
                       _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
         elif ctx.needs_input_grad[2]:
             db = g.sum(dim=(0, 2, 3), dtype=torch.float32)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 _WGRAD_WS: Dict[tuple, torch.Tensor] = {}
@@ -185,12 +195,18 @@ class Conv3x3(nn.Conv2d):
                 if p.requires_grad:
                     p.grad = g if p.grad is None else p.grad + g
 
-    def forward(self, x):
-        if (self.native and x.is_cuda and torch.is_autocast_enabled() and self.stride == (1, 1)
-                and tuple(self.weight.shape) == (256, 256, 3, 3) and tuple(x.shape[1:]) == (256, 12, 12)):
+    def runs_native(self, x) -> bool:
+        return (self.native and x.is_cuda and torch.is_autocast_enabled() and self.stride == (1, 1)
+                and tuple(self.weight.shape) == (256, 256, 3, 3) and tuple(x.shape[1:]) == (256, 12, 12))
+
+    def forward(self, x, want_stats: bool = False):
+        """want_stats (native path only): returns (y, per-image column sums of y), see _Conv3x3Native.forward."""
+        if self.runs_native(x):
             with torch.autocast("cuda", enabled=False):
                 xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-                return _Conv3x3Native.apply(xb, self.weight, self.bias, self._packed)
+                return _Conv3x3Native.apply(xb, self.weight, self.bias, self._packed, want_stats)
+        if want_stats:
+            raise ValueError("column sums come from the native convolution only")
         return super().forward(x)
 
 
@@ -210,16 +226,24 @@ class _BNActNative(torch.autograd.Function):
     x, residual: bf16 [N, C, H, W] in channels_last memory.  Running statistics are updated in place."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, stats=None):
         n, c, h, w = x.shape
         rows = n * h * w
         y = torch.empty_like(x)                       # keeps the channels_last strides
         save_mean = torch.empty(c, dtype=torch.float32, device=x.device)
         save_invstd = torch.empty_like(save_mean)
         ws = _bn_workspace(c, x.device)
-        _lib.call("mz_bn_relu_train_fwd", _lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma.detach()), _lib.ptr(beta.detach()),
-                  _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum), 1, rows, c, _lib.ptr(y),
-                  _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
+        if stats is None:
+            _lib.call("mz_bn_relu_train_fwd", _lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma.detach()),
+                      _lib.ptr(beta.detach()), _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum),
+                      1, rows, c, _lib.ptr(y), _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(ws), ws.numel() * 8,
+                      _lib.current_stream())
+        else:                                         # column sums of x came with x (per image, from the convolution)
+            _lib.expect(stats, "stats", torch.float64, (stats.shape[0], 2, c))
+            _lib.call("mz_bn_relu_train_fwd_stats", _lib.ptr(x), _lib.ptr(residual), _lib.ptr(gamma.detach()),
+                      _lib.ptr(beta.detach()), _lib.ptr(running_mean), _lib.ptr(running_var), float(eps), float(momentum),
+                      1, rows, c, _lib.ptr(y), _lib.ptr(save_mean), _lib.ptr(save_invstd), _lib.ptr(stats),
+                      stats.shape[0], _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
         ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
         ctx.has_residual = residual is not None
         return y
@@ -237,7 +261,7 @@ class _BNActNative(torch.autograd.Function):
         _lib.call("mz_bn_relu_train_bwd", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                   _lib.ptr(save_mean), _lib.ptr(save_invstd), 1, n * h * w, c, _lib.ptr(dx), _lib.ptr(dres),
                   _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
-        return dx, dres, dgamma, dbeta, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None
 
 
 _BN_COUNTS: Optional[dict] = None
@@ -260,13 +284,27 @@ class count_bn_applications:
         return False
 
 
-def bn_act(bn: nn.BatchNorm2d, x, residual=None):
+def _bn_native(bn: nn.BatchNorm2d, x) -> bool:
+    return (getattr(bn, "native", False) and bn.training and x.is_cuda and x.dtype == torch.bfloat16
+            and torch.is_autocast_enabled() and x.dim() == 4 and x.shape[1] in (64, 128, 256, 512)
+            and x.is_contiguous(memory_format=torch.channels_last) and bn.track_running_stats and bn.momentum is not None)
+
+
+def conv_bn_act(conv: "Conv3x3", bn: nn.BatchNorm2d, x, residual=None):
+    """relu(bn(conv(x)) [+ residual]): where both run on this library's kernels the convolution hands the
+    BatchNorm its column sums, and the BatchNorm's own statistics pass over the activations falls away."""
+    if conv.runs_native(x) and getattr(bn, "native", False) and bn.training and bn.track_running_stats \
+            and bn.momentum is not None:
+        y, stats = conv(x, want_stats=True)
+        return bn_act(bn, y, residual, stats=stats)
+    return bn_act(bn, conv(x), residual)
+
+
+def bn_act(bn: nn.BatchNorm2d, x, residual=None, stats=None):
     """relu(bn(x) [+ residual]) (model.py:155-158, :166, :237).  The fused kernels serve training-mode BatchNorm on
     bf16 channels_last activations - what the native convolutions produce - when the learner computes in bf16;
     everything else goes through torch."""
-    if (getattr(bn, "native", False) and bn.training and x.is_cuda and x.dtype == torch.bfloat16
-            and torch.is_autocast_enabled() and x.dim() == 4 and x.shape[1] in (64, 128, 256, 512)
-            and x.is_contiguous(memory_format=torch.channels_last) and bn.track_running_stats and bn.momentum is not None):
+    if _bn_native(bn, x):
         with torch.autocast("cuda", enabled=False):
             if residual is not None:
                 residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -275,7 +313,9 @@ def bn_act(bn: nn.BatchNorm2d, x, residual=None):
             else:
                 bn.num_batches_tracked.add_(1)
             return _BNActNative.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                      bn.momentum)
+                                      bn.momentum, stats)
+    if stats is not None:
+        raise ValueError("column sums are for the fused BatchNorm path only")
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -292,8 +332,8 @@ class _Res(nn.Module):
         self.bn2 = nn.BatchNorm2d(c)
 
     def forward(self, x):
-        y = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(y), residual=x)
+        y = conv_bn_act(self.conv1, self.bn1, x)
+        return conv_bn_act(self.conv2, self.bn2, y, residual=x)
 
 
 class _Down(nn.Module):
@@ -357,7 +397,7 @@ class _Dynamics(nn.Module):
         # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
         w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
         x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
-        x = bn_act(self.bn, self.conv_state(x))
+        x = conv_bn_act(self.conv_state, self.bn, x)
         for b in self.resblocks:
             x = b(x)
         return x

@@ -305,3 +305,57 @@ def test_deferred_weight_gradients_equal_the_per_step_ones():
         tol = 1e-4 if k.startswith("dynamics.") and ("conv_state" in k or "resblocks" in k) and "conv" in k else 3e-2
         err = (plain[k] - fused[k]).abs().max().item()
         assert err <= tol * scale, (k, err, scale)
+
+
+def test_batchnorm_statistics_from_the_convolution():
+    """conv_bn_act (the convolution writes per-image column sums of its rounded outputs, the BatchNorm takes its
+    batch statistics from them) against the convolution followed by the BatchNorm's own statistics pass: same
+    outputs, running statistics and gradients up to the float32 rounding of the 144-pixel partial sums; and the
+    sums themselves against a float64 reduction of the convolution's output."""
+    import torch.nn as nn
+    from muzero_amd import _lib, mfma
+    from muzero_amd.learner import Conv3x3, bn_act, conv_bn_act
+    torch.manual_seed(3)
+    n = 24
+    x = torch.randn(n, 256, 12, 12, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn_like(x).contiguous(memory_format=torch.channels_last)
+    up = torch.randn_like(x).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (False, True):
+        torch.manual_seed(5)
+        conv, bn = Conv3x3(256, 256).cuda(), nn.BatchNorm2d(256).cuda()
+        bn.native = True
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.2, 0.2)
+        xi = x.clone().requires_grad_()
+        ri = res.clone().requires_grad_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv_bn_act(conv, bn, xi, ri) if fused else bn_act(bn, conv(xi), ri)
+        y.backward(up)
+        outs.append((y.detach().float(), bn.running_mean.clone(), bn.running_var.clone(), xi.grad.float(), ri.grad.float(),
+                     conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), int(bn.num_batches_tracked)))
+    a, b = outs
+    assert a[8] == b[8] == 1
+    for i, tol in ((0, 1e-2), (1, 1e-5), (2, 1e-5), (3, 2e-2), (4, 0.0), (5, 2e-3), (6, 2e-3), (7, 2e-3)):
+        scale = a[i].abs().max().item()
+        assert (a[i] - b[i]).abs().max().item() <= tol * scale + 1e-12, (i, (a[i] - b[i]).abs().max().item(), scale)
+    assert (a[0] != b[0]).float().mean().item() < 0.01        # the odd last-bit difference only
+
+    # the sums themselves
+    w = torch.randn(256, 256, 3, 3, device="cuda") / 48.0
+    bias = torch.randn(256, device="cuda") * 0.1
+    wpk = mfma.pack_weights(w.cpu(), 256).cuda()
+    xh = x.permute(0, 2, 3, 1)
+    out = torch.empty_like(xh)
+    stats = torch.empty(n, 2, 256, dtype=torch.float64, device="cuda")
+    _lib.call("mz_conv3x3_bf16_stats", _lib.ptr(xh), _lib.ptr(wpk), _lib.ptr(bias), _lib.ptr(out), _lib.ptr(stats), n,
+              _lib.current_stream())
+    ref = torch.empty_like(xh)
+    _lib.call("mz_conv3x3_bf16", _lib.ptr(xh), None, 0, _lib.ptr(wpk), _lib.ptr(bias), None, _lib.ptr(ref), None, None, None,
+              n, 12, 12, 256, 256, 1, 0, _lib.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    o = out.double().reshape(n, 144, 256)
+    assert torch.allclose(stats[:, 0], o.sum(1), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(stats[:, 1], (o * o).sum(1), rtol=1e-6, atol=1e-5)
