@@ -20,7 +20,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/x
 python3 tools/top_kernels.py $out/x3 14 > $out/${tag}_x3_kernels.txt
 echo "x3 pass done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/train -- python3 tools/profile_train.py 128 bf16 native graphed > /dev/null 2> $out/train.err
-python3 tools/last_window.py $out/train 10.8 40 > $out/${tag}_train_update.txt
+python3 tools/last_window.py $out/train 10.7 40 > $out/${tag}_train_update.txt
 echo "train pass done"
 # keep only what the summaries need (the traces are tens of MB)
 find $out -name "*kernel_trace.csv" -delete
