@@ -41,7 +41,7 @@ struct Cfg {
 #endif
 using ConvStem = Cfg<96, 96, 256, 2, MZ_STEM_TH, MZ_STEM_TW, 96, 96, MZ_STEM_MINW, 2, MZ_STEM_NW>;  // representation.conv1
 using ConvStemRot = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2, 2, 8>;   // the same layer on the rotating, tiled observation
-using ConvDown0 = Cfg<256, 128, 128, 2, 8, 8, 48, 48, 2, 2, 8>;   // downsample.0.conv
+using ConvDown0 = Cfg<256, 64, 128, 2, 8, 8, 48, 48, 2, 2, 8>;    // downsample.0.conv (64-channel chunks: -7 % against 128)
 using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, 3, 2, 4>;   // downsample.0.blocks
 using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, 2, 2, 8>;  // downsample.1.conv
 
