@@ -31,6 +31,17 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_pack_linear", one, None, 601, 250, 1, one, None, None, match="multiple")
     _fails("mz_conv_wgrad_bf16", one, one, 4, 24, 24, 128, 128, one, None, one, 1 << 30, None, match="12x12")
     _fails("mz_conv_wgrad_bf16", one, one, 4, 12, 12, 256, 256, one, None, one, 16, None, match="workspace")
+    two = (C.c_void_p * 2)(16, 16)
+    _fails("mz_conv_wgrad_bf16_multi", two, two, 9, 4, 12, 12, 256, 256, one, None, one, 1 << 30, None, match="n_segments")
+    _fails("mz_conv_wgrad_bf16_multi", two, two, 2, 4, 24, 24, 128, 128, one, None, one, 1 << 30, None, match="12x12")
+    _fails("mz_conv_wgrad_bf16_multi", (C.c_void_p * 2)(16, None), two, 2, 4, 12, 12, 256, 256, one, None, one, 1 << 30,
+           None, match="segment 1")
+    _fails("mz_weights_pack_many", two, (C.c_void_p * 2)(16, None), None, 2, 256, 256, 256, None, match="item 1")
+    _fails("mz_weights_pack_many", two, two, None, 2, 250, 96, 96, None, match="fragments")
+    _fails("mz_conv3x3_bf16_stats", one, one, one, one, None, 4, None, match="null")
+    _fails("mz_bn_relu_train_fwd_stats", one, None, one, one, None, None, 1e-5, 0.1, 1, 100, 256, one, one, one, None, 4,
+           one, 1 << 30, None, match="stats")
+    _fails("mz_conv_chain_mid_bf16", one, one, 0, one, 4, None, match="n_layers")
     _fails("mz_bn_relu_train_fwd", one, None, one, one, None, None, 1e-5, 0.1, 1, 100, 100, one, one, one, one, 1 << 30, None,
            match="C in")
     _fails("mz_bn_relu_train_bwd", one, one, None, one, one, one, 1, 100, 256, one, None, one, one, one, 1 << 30, None,
