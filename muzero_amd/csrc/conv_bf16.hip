@@ -78,41 +78,132 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
 
 // The same window from the rotating, tiled observation [H][W/16][D][56] (prep.hip): the patch's 17 input
 // columns - 16 output-stride columns and the one to their left - are exactly one tile's runs (halo pixel, 16
-// pixels, padding: 7 units of 16 bytes per slot), read with 16-byte loads and scattered to
-// [pixel][3*D channels] in LDS two bytes at a time.
+// pixels, padding: 7 units of 16 bytes per slot).  A run holds one slot's three channels of consecutive pixels;
+// the window wants every slot's channels of one pixel side by side.  A lane takes 8 pixels of one slot (48
+// bytes), the four lanes of a quad hold four neighbouring slots, and a 4x4 transposition inside the quad (two
+// exchange steps over the data-parallel-primitive lane network) leaves each lane with two pixels of all four
+// slots: 24 contiguous, 8-byte-aligned bytes of the window per pixel, written as three 8-byte stores.  Writing
+// the values two bytes at a time instead costs eight times the LDS instructions, most of them bank conflicts.
+// The 17th pixel of each run (three values) is scattered two bytes at a time.
+__device__ __forceinline__ unsigned quad_xor1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ unsigned quad_xor2(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+}
+
 template <class C>
 __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, int iy0, int ix0, int tid) {
-  static_assert(C::IW == 17 && C::CIN % 3 == 0 && C::CINC == C::CIN && C::WIN % 16 == 0, "tile = patch width");
+  static_assert(C::IW == 17 && C::IH == 17 && C::CIN == 96 && C::CINC == C::CIN && C::WIN % 16 == 0 &&
+                C::THREADS == 512 && C::ROWB % 8 == 0, "one 16-pixel tile, 32 slots, eight wavefronts");
   constexpr int D = C::CIN / 3, TPR = C::WIN / 16;  // slots, tiles per image row
-  constexpr int RUN = 56, UPS = RUN / 8;            // values and 16-byte units per slot run
+  constexpr int RUN = 56;                           // values per slot run
+  typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+  typedef unsigned __attribute__((ext_vector_type(2))) u32x2;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xt = (ix0 + 1) / 16;
-  constexpr int MAIN = C::IH * D * UPS;  // 16-byte units: rows x slots x 7
-  // every load of the window is in flight before the first LDS write waits for one (loads of rows outside the
-  // image are redirected to row 0 and zeroed afterwards, so that each register is written unconditionally)
-  constexpr int ROUNDS = (MAIN + C::THREADS - 1) / C::THREADS;
-  bf16x8 v[ROUNDS];
+  const int s = lane & 31, h = lane >> 5;  // slot; which 8 pixels of the run
+  const bool b0 = lane & 1, b1 = lane & 2;
+  // rows wave and wave + 8 in every wavefront; row 16 in wavefront 0, the 17th pixels in the others
+  constexpr int ROUNDS = 3;
+  u32x4 v[ROUNDS][3];
+  auto row_of = [&](int i) { return i < 2 ? wave + 8 * i : 16; };
+  auto clamp_row = [&](int row) {
+    const int iy = iy0 + row;
+    return (iy >= 0 && iy < C::HIN) ? iy : 0;  // rows outside the image load row 0 and are zeroed afterwards
+  };
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
-    int u = tid + i * C::THREADS;
-    u = u < MAIN ? u : MAIN - 1;
-    const int row = u / (D * UPS), rem = u - row * (D * UPS);   // rem = slot * 7 + unit: the row's runs are contiguous
-    int iy = iy0 + row;
-    iy = (iy >= 0 && iy < C::HIN) ? iy : 0;
-    v[i] = *reinterpret_cast<const bf16x8*>(src + ((long)iy * TPR + xt) * (D * RUN) + rem * 8);
+    if (i == 2 && wave != 0) break;
+    const u32x4* p = reinterpret_cast<const u32x4*>(
+        src + (((long)clamp_row(row_of(i)) * TPR + xt) * D + s) * RUN + h * 24);
+    v[i][0] = p[0]; v[i][1] = p[1]; v[i][2] = p[2];
   }
+  // the 17th pixels: 17 rows x 32 slots, two per lane of wavefronts 1..7
+  u32x2 last[2];
+  int last_row[2], last_s[2];
+  if (wave != 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int n = (wave - 1) * 64 + lane + 448 * i;
+      n = n < C::IH * D ? n : C::IH * D - 1;
+      last_row[i] = n / D; last_s[i] = n % D;
+      last[i] = *reinterpret_cast<const u32x2*>(
+          src + (((long)clamp_row(last_row[i]) * TPR + xt) * D + last_s[i]) * RUN + 48);
+    }
+  }
+
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
-    const int u = tid + i * C::THREADS;
-    if (u < MAIN) {
-      const int row = u / (D * UPS), rem = u - row * (D * UPS);
-      const int s = rem / UPS, k = rem - s * UPS;
-      const int iy = iy0 + row;
-      const bool inside = iy >= 0 && iy < C::HIN;
-      char* base = lds + (row * C::IW) * C::ROWB + s * 6;
+    if (i == 2 && wave != 0) break;
+    const int row = row_of(i);
+    const int iy = iy0 + row;
+    const unsigned keep = (iy >= 0 && iy < C::HIN) ? 0xffffffffu : 0u;
+    // blk[d][0..2]: this slot's pixels 2d, 2d+1 (of the lane's eight) - the block lane d of the quad wants
+    unsigned blk[4][3];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int el = k * 8 + e, px = el / 3, r = el - px * 3;
-        if (el < 51) *reinterpret_cast<__bf16*>(base + px * C::ROWB + r * 2) = inside ? v[i][e] : (__bf16)0.f;
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) blk[d][c] = v[i][(d * 3 + c) / 4][(d * 3 + c) % 4] & keep;
+    // step 1, partner lane ^ 2: keep the blocks for lanes with this lane's bit 1, receive the partner's
+    unsigned ka[3], kb[3], ra[3], rb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ka[c] = b1 ? blk[2][c] : blk[0][c];
+      kb[c] = b1 ? blk[3][c] : blk[1][c];
+      ra[c] = quad_xor2(b1 ? blk[0][c] : blk[2][c]);
+      rb[c] = quad_xor2(b1 ? blk[1][c] : blk[3][c]);
+    }
+    // step 2, partner lane ^ 1: x[j] is the block of slot (lane ^ j) for this lane's two pixels
+    unsigned x[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      x[0][c] = b0 ? kb[c] : ka[c];
+      x[1][c] = quad_xor1(b0 ? ka[c] : kb[c]);
+      x[2][c] = b0 ? rb[c] : ra[c];
+      x[3][c] = quad_xor1(b0 ? ra[c] : rb[c]);
+    }
+    // order by slot: sl[q] = x[q ^ (lane & 3)]
+    unsigned sl[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned p0 = b1 ? x[2][c] : x[0][c], p1 = b1 ? x[3][c] : x[1][c];
+      const unsigned p2 = b1 ? x[0][c] : x[2][c], p3 = b1 ? x[1][c] : x[3][c];
+      sl[0][c] = b0 ? p1 : p0; sl[1][c] = b0 ? p0 : p1;
+      sl[2][c] = b0 ? p3 : p2; sl[3][c] = b0 ? p2 : p3;
+    }
+    // a block is (p r0, p r1 | p r2, p' r0 | p' r1, p' r2) for the pixel pair p, p'
+    const int px = h * 8 + (lane & 3) * 2;
+    char* dst = lds + (row * C::IW + px) * C::ROWB + (s & ~3) * 6;
+    unsigned o[2][6];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned* e = sl[2 * q];
+      const unsigned* f = sl[2 * q + 1];
+      o[0][3 * q + 0] = e[0];
+      o[0][3 * q + 1] = (e[1] & 0xffffu) | (f[0] << 16);
+      o[0][3 * q + 2] = (f[0] >> 16) | (f[1] << 16);
+      o[1][3 * q + 0] = (e[1] >> 16) | (e[2] << 16);
+      o[1][3 * q + 1] = (e[2] >> 16) | (f[1] & 0xffff0000u);
+      o[1][3 * q + 2] = f[2];
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        *reinterpret_cast<u32x2*>(dst + p * C::ROWB + c * 8) = u32x2{o[p][2 * c], o[p][2 * c + 1]};
+  }
+  if (wave != 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = (wave - 1) * 64 + lane + 448 * i;
+      if (n < C::IH * D) {
+        const int iy = iy0 + last_row[i];
+        const unsigned keep = (iy >= 0 && iy < C::HIN) ? 0xffffffffu : 0u;
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(lds + (last_row[i] * C::IW + 16) * C::ROWB + last_s[i] * 6);
+        d16[0] = (unsigned short)(last[i][0] & keep);
+        d16[1] = (unsigned short)((last[i][0] & keep) >> 16);
+        d16[2] = (unsigned short)(last[i][1] & keep);
       }
     }
   }
