@@ -72,7 +72,7 @@ __device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const 
         v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
       }
     }
-    *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = v;
+    *reinterpret_cast<bf16x8*>(lds + py * C::ROWP + px * C::ROWB + cu * 16) = v;
   }
 }
 
@@ -174,7 +174,7 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, in
     }
     // a block is (p r0, p r1 | p r2, p' r0 | p' r1, p' r2) for the pixel pair p, p'
     const int px = h * 8 + (lane & 3) * 2;
-    char* dst = lds + (row * C::IW + px) * C::ROWB + (s & ~3) * 6;
+    char* dst = lds + row * C::ROWP + px * C::ROWB + (s & ~3) * 6;
     unsigned o[2][6];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -200,7 +200,7 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, in
       if (n < C::IH * D) {
         const int iy = iy0 + last_row[i];
         const unsigned keep = (iy >= 0 && iy < C::HIN) ? 0xffffffffu : 0u;
-        unsigned short* d16 = reinterpret_cast<unsigned short*>(lds + (last_row[i] * C::IW + 16) * C::ROWB + last_s[i] * 6);
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(lds + last_row[i] * C::ROWP + 16 * C::ROWB + last_s[i] * 6);
         d16[0] = (unsigned short)(last[i][0] & keep);
         d16[1] = (unsigned short)((last[i][0] & keep) >> 16);
         d16[2] = (unsigned short)(last[i][1] & keep);
@@ -242,12 +242,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   auto wfrag = [&](int step_off, int nt) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane + nt * 1024, step_off, 0));
   };
-  bf16x8 w0[WN], w1[WN];
+  // a ring of PF + 1 fragment sets: step st multiplies set st % (PF + 1) while the loads of step st + PF land
+  // in set (st + PF) % (PF + 1); the k-steps of a channel chunk are a multiple of the ring, so the (unrolled)
+  // indices are the same in every chunk
+  constexpr int RING = C::PF + 1;
+  static_assert((9 * KC) % RING == 0, "k-steps per channel chunk must be a multiple of the prefetch ring");
+  bf16x8 wq[RING][WN];
 #pragma unroll
-  for (int nt = 0; nt < WN; ++nt) {
-    w0[nt] = wfrag(0, nt);
-    if constexpr (C::PF == 2) w1[nt] = wfrag(WSTEP, nt);
-  }
+  for (int pf = 0; pf < C::PF; ++pf)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) wq[pf][nt] = wfrag(pf * WSTEP, nt);
   int wp = C::PF * WSTEP;
 
   // LDS byte address of this lane's pixel (tap 0, first k-step) in each 16-pixel tile; every
@@ -260,12 +264,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
     int m = mt * 16 + r16;
     if (m >= C::M) m = C::M - 1;  // padding rows recompute the last pixel; never stored
     const int py = m / C::TW, px = m % C::TW;
-    abase[mt] = lds_base + (py * C::S * C::IW + px * C::S) * C::ROWB + kq * 16;
+    abase[mt] = lds_base + py * C::S * C::ROWP + px * C::S * C::ROWB + kq * 16;
   }
   constexpr int NS = 9 * KC;  // k-steps per channel chunk
   auto step_offset = [](int st) {
     const int tap = st / KC, kc = st % KC;
-    return ((tap / 3) * C::IW + tap % 3) * C::ROWB + kc * 64;
+    return (tap / 3) * C::ROWP + (tap % 3) * C::ROWB + kc * 64;
   };
 
   for (int cc = 0; cc < C::NCC; ++cc) {
@@ -280,15 +284,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
     for (int mt = 0; mt < MT; ++mt) af[mt] = *(lds_frag_ptr)(abase[mt]);
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
-      bf16x8 w2[WN];
 #pragma unroll
-      for (int nt = 0; nt < WN; ++nt) w2[nt] = wfrag(wp, nt);  // PF k-steps ahead
+      for (int nt = 0; nt < WN; ++nt) wq[(st + C::PF) % RING][nt] = wfrag(wp, nt);  // PF k-steps ahead
       wp += WSTEP;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], af[mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[st % RING][nt], af[mt], acc[mt][nt], 0, 0, 0);
         if (st + 1 < NS) af[mt] = *(lds_frag_ptr)(abase[mt] + step_offset(st + 1));
       }
       __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -298,15 +301,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nt = 0; nt < WN; ++nt) {
-        if constexpr (C::PF == 2) {
-          w0[nt] = w1[nt];
-          w1[nt] = w2[nt];
-        } else {
-          w0[nt] = w2[nt];
-        }
-      }
     }
   }
 

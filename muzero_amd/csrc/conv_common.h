@@ -9,11 +9,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef MZ_ROWPAD
+#define MZ_ROWPAD 1
+#endif
 template <int CIN_, int CINC_, int COUT_, int S_, int TH_, int TW_, int HIN_, int WIN_, int MINW_, int PF_ = 2, int NW_ = 4>
 struct Cfg {
   static constexpr int NW = NW_;          // wavefronts per workgroup; they split the output channels
   static constexpr int THREADS = 64 * NW_;
-  static constexpr int PF = PF_;  // weight prefetch distance in k-steps (1 or 2)
+  static constexpr int PF = PF_;  // weight prefetch distance in k-steps; 9 * KC must be a multiple of PF + 1
   static constexpr int CIN = CIN_, CINC = CINC_, COUT = COUT_, S = S_, TH = TH_, TW = TW_, HIN = HIN_, WIN = WIN_;
   static constexpr int MINW = MINW_;
   static constexpr int HO = (HIN - 1) / S + 1, WO = (WIN - 1) / S + 1;
@@ -23,7 +26,12 @@ struct Cfg {
   static constexpr int ROWB = CINC * 2 + 16;
   static constexpr int KC = CINC / 32, NCC = CIN / CINC;
   static constexpr int NTILES = COUT / 16, WN = NTILES / NW;
-  static constexpr int LDS_BYTES = IH * IW * ROWB;
+  // bytes between window rows.  A stride-2 operand read puts the 16 lanes of a pixel tile on every second pixel
+  // of two window rows two apart: with an odd pixel pitch (in 16-byte units) the eight pixels of a row fall on
+  // eight different even units of the 16 the banks hold, and the two rows coincide - no conflict - only if twice
+  // the row pitch is a multiple of 16 units, so the row pitch is padded to a multiple of 128 bytes
+  static constexpr int ROWP = (S == 2 && MZ_ROWPAD) ? (IW * ROWB + 127) / 128 * 128 : IW * ROWB;
+  static constexpr int LDS_BYTES = IH * ROWP;
   static constexpr int KSTEPS = NCC * 9 * KC;
   static_assert(HO % TH == 0 && WO % TW == 0, "patches must tile the output");
   static_assert(CIN % CINC == 0 && CINC % 32 == 0 && COUT % (16 * NW) == 0, "channel tiling");
@@ -41,7 +49,7 @@ struct Cfg {
 #endif
 using ConvStem = Cfg<96, 96, 256, 2, MZ_STEM_TH, MZ_STEM_TW, 96, 96, MZ_STEM_MINW, 2, MZ_STEM_NW>;  // representation.conv1
 using ConvStemRot = Cfg<96, 96, 256, 2, 8, 8, 96, 96, 2, 2, 8>;   // the same layer on the rotating, tiled observation
-using ConvDown0 = Cfg<256, 64, 128, 2, 8, 8, 48, 48, 2, 2, 8>;    // downsample.0.conv (64-channel chunks: -7 % against 128)
+using ConvDown0 = Cfg<256, 64, 128, 2, 8, 8, 48, 48, 2, 2, 8>; // downsample.0.conv (64-channel chunks: -7 % against 128)
 using ConvMid = Cfg<128, 128, 128, 1, 12, 12, 24, 24, 3, 2, 4>;   // downsample.0.blocks
 using ConvDown1 = Cfg<128, 128, 256, 2, 4, 12, 24, 24, 2, 2, 8>;  // downsample.1.conv
 
