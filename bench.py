@@ -297,7 +297,7 @@ def main():
         # + A*20+12 written by the expansion + (D+1)*32 for the backup at mean depth D ~ 4.
         tree_bytes = B * (4 * (A * 20 + 20) + A * 20 + 12 + 5 * 32)
         out["secondary_kernels"] = [
-            {"kernel": "expand_backup_select_kernel (tree step)", "bound": "hbm (latency-bound dependent loads)",
+            {"kernel": "expand_backup_select_staged_kernel (tree step, tree staged in LDS)", "bound": "hbm (latency-bound: two load round trips, then ALU latency)",
              "launch_us": tree_s * 1e6, "achieved": tree_bytes / tree_s / 1e9, "peak": 8000.0, "unit": "GB/s",
              "frac": tree_bytes / tree_s / 8e12},
             {"kernel": "heads_kernel (3 MLPs + softmax + support decode)", "bound": "latency (4 dependent phases)",

@@ -107,7 +107,8 @@ int mz_tree_expand_backup(void* ws, const mz_tree_layout* L, const float* priors
 
 /* mz_tree_expand_backup for simulation s followed by mz_tree_select for simulation s + 1 in
  * one launch (both work wavefront-per-game on the same game, so no grid-wide ordering is
- * needed).  Same results as the two calls in sequence; saves a launch per simulation. */
+ * needed).  Same results as the two calls in sequence; saves a launch per simulation.  Trees of
+ * at most 64 nodes and 1024 edge records (max_nodes * A) are copied to LDS first and walked there. */
 int mz_tree_expand_backup_select(void* ws, const mz_tree_layout* L, const float* priors, const float* value,
                                  const float* reward, int32_t wave, double gamma, const double* pbc_table,
                                  const double* sqrt_table, int32_t table_len, mz_stream_t stream);

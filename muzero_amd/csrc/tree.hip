@@ -5,6 +5,8 @@
 // arithmetic step by step, and a fused multiply-add would change the rounding.
 #pragma clang fp contract(off)
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -329,6 +331,227 @@ __global__ __launch_bounds__(kBlock) void expand_backup_select_kernel(TreeView t
   select_game(t, pbc, sq, table_len, b, lane);
 }
 
+// The same step with the game's tree staged in LDS.  The kernel above is a chain of dependent global loads
+// (bookkeeping scalars -> path -> edge records -> one row of edge records per level of the descent), each a
+// round trip to L2 or beyond, because the convolutions between two steps flush the tree out of the nearer
+// caches.  Here one round trip fetches everything whose address is known up front (scalars, the path, every
+// node's reward, the new priors, the first entries of the score tables), a second one fetches the edge records
+// of all num_nodes rows into LDS, and backup and descent then run on the LDS copy; the records they change are
+// written to LDS and to global memory.  Same arithmetic in the same order as the kernel above.
+constexpr int kStagedIters = 16;      // edge records per lane: trees of up to 1024 edges
+constexpr int kStagedTable = 256;     // score-table entries kept in LDS; larger parent counts read global memory
+
+__host__ __device__ inline size_t staged_wave_bytes(int N, int A) {
+  return ((size_t)N * A * 20 + (size_t)N * 32 + 15) / 16 * 16;
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
+    TreeView t, const float* __restrict__ priors, const float* __restrict__ value, const float* __restrict__ reward,
+    int wave, double gamma, const double* __restrict__ pbc, const double* __restrict__ sq, int table_len) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * WPB + w;
+  const int A = t.A, N = t.N;
+  const int staged = table_len < kStagedTable ? table_len : kStagedTable;
+  double* tab_pbc = reinterpret_cast<double*>(smem);
+  double* tab_sq = tab_pbc + kStagedTable;
+  for (int i = threadIdx.x; i < staged; i += WPB * 64) {
+    tab_pbc[i] = pbc[i];
+    tab_sq[i] = sq[i];
+  }
+  char* mine = smem + 2 * kStagedTable * sizeof(double) + (size_t)w * staged_wave_bytes(N, A);
+  double* l_ws = reinterpret_cast<double*>(mine);
+  double* rwd = l_ws + (size_t)N * A;
+  double* val = rwd + N;
+  double* nrew = val + N;
+  int* l_visit = reinterpret_cast<int*>(nrew + N);
+  int* l_child = l_visit + (size_t)N * A;
+  float* l_prior = reinterpret_cast<float*>(l_child + (size_t)N * A);
+  int* l_pn = reinterpret_cast<int*>(l_prior + (size_t)N * A);
+  int* l_pa = l_pn + N;
+
+  bool live = b < t.B;
+  const int bb = live ? b : 0;
+  // ---- round trip 1: everything with a known address
+  const int e = wave_uniform(t.num_nodes[bb]);
+  const int len = wave_uniform(t.path_len[bb]);
+  const int parent = wave_uniform(t.leaf_parent[bb]);
+  const int act = wave_uniform(t.leaf_action[bb]);
+  const double leaf_reward = (double)reward[bb];
+  const double leaf_value = (double)value[bb];
+  const int root_n = t.root_visit[bb];
+  const double root_ws = t.root_value_sum[bb];
+  const double plo = t.minmax[2 * bb], phi = t.minmax[2 * bb + 1];
+  const bool root64 = t.root_is_f64[bb] != 0;
+  const size_t nbase = (size_t)bb * N;
+  const int my_pn = lane < N ? t.path_node[nbase + lane] : 0;
+  const int my_pa = lane < N ? t.path_action[nbase + lane] : 0;
+  const double my_rew = lane < N ? t.reward[nbase + lane] : 0.0;
+  const float new_prior = lane < A ? priors[(size_t)bb * A + lane] : 0.f;
+  const double root_p64 = lane < A ? t.root_prior64[(size_t)bb * A + lane] : 0.0;
+  if (live && (e >= N || len <= 0)) {
+    if (lane == 0) t.status[b] = 2;
+    live = false;
+  }
+  // ---- round trip 2: the edge records of rows 0 .. e-1
+  const size_t ebase = nbase * A;
+  const int cnt = live ? e * A : 0;
+  int r_visit[kStagedIters], r_child[kStagedIters];
+  float r_prior[kStagedIters];
+  double r_ws[kStagedIters];
+#pragma unroll
+  for (int it = 0; it < kStagedIters; ++it) {
+    const int i = it * 64 + lane;
+    if (it * 64 < cnt) {
+      const int j = i < cnt ? i : cnt - 1;
+      r_visit[it] = t.visit[ebase + j];
+      r_child[it] = t.child[ebase + j];
+      r_prior[it] = t.prior[ebase + j];
+      r_ws[it] = t.value_sum[ebase + j];
+    }
+  }
+  if (lane < N) {
+    l_pn[lane] = my_pn;
+    l_pa[lane] = my_pa;
+    nrew[lane] = my_rew;
+  }
+#pragma unroll
+  for (int it = 0; it < kStagedIters; ++it) {
+    const int i = it * 64 + lane;
+    if (it * 64 < cnt && i < cnt) {
+      l_visit[i] = r_visit[it];
+      l_child[i] = r_child[it];
+      l_prior[i] = r_prior[it];
+      l_ws[i] = r_ws[it];
+    }
+  }
+  __syncthreads();  // the score tables (and, within each wavefront, its own tree) are in LDS
+  if (!live) return;
+
+  // ---- expansion: a fresh row of A edge records behind (parent, act)
+  const int erow = e * A;
+  if (lane < A) {
+    l_prior[erow + lane] = new_prior;
+    l_visit[erow + lane] = 0;
+    l_ws[erow + lane] = 0.0;
+    l_child[erow + lane] = -1;
+    t.prior[ebase + erow + lane] = new_prior;
+    t.visit[ebase + erow + lane] = 0;
+    t.value_sum[ebase + erow + lane] = 0.0;
+    t.child[ebase + erow + lane] = -1;
+  }
+  if (lane == 0) {
+    l_child[parent * A + act] = e;
+    t.child[ebase + parent * A + act] = e;
+    t.reward[nbase + e] = leaf_reward;
+    t.num_nodes[b] = e + 1;
+  }
+  for (int d = lane; d < len; d += 64) rwd[d] = d == len - 1 ? leaf_reward : nrew[l_pn[d + 1]];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- value = reward + gamma * value, leaf first (model.py:522-526)
+  double v = leaf_value;
+  for (int d = len - 1; d >= 0; --d) {
+    if (lane == 0) val[d] = v;
+    v = rwd[d] + gamma * v;
+  }
+  const double root_add = v;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  double lo = __builtin_inf(), hi = -__builtin_inf();
+  for (int d = lane; d < len; d += 64) {
+    const int idx = l_pn[d] * A + l_pa[d];
+    double ws = l_ws[idx];
+    int n = l_visit[idx];
+    const double add = val[d];
+    for (int k = 0; k < wave; ++k) {
+      ws += add;
+      n += 1;
+      const double q = ws / (double)n;
+      lo = q < lo ? q : lo;
+      hi = q > hi ? q : hi;
+    }
+    l_ws[idx] = ws;
+    l_visit[idx] = n;
+    t.value_sum[ebase + idx] = ws;
+    t.visit[ebase + idx] = n;
+  }
+  int parent_n = root_n;
+  if (lane == 0) {
+    double ws = root_ws;
+    int n = root_n;
+    for (int k = 0; k < wave; ++k) {
+      ws += root_add;
+      n += 1;
+      const double q = ws / (double)n;
+      lo = q < lo ? q : lo;
+      hi = q > hi ? q : hi;
+    }
+    t.root_value_sum[b] = ws;
+    t.root_visit[b] = n;
+    parent_n = n;
+  }
+  parent_n = wave_uniform(parent_n);
+  lo = -wave_max_f64(-lo);
+  hi = wave_max_f64(hi);
+  lo = lo < plo ? lo : plo;
+  hi = hi > phi ? hi : phi;
+  if (lane == 0) {
+    t.minmax[2 * b] = lo;
+    t.minmax[2 * b + 1] = hi;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- descent of the next simulation (select_game on the LDS copy)
+  const double ninf = -__builtin_inf();
+  int node = 0, depth = 0, bad = 0;
+  while (true) {
+    const int row = node * A;
+    int n = 0, kid = -1;
+    double score = ninf;
+    if (lane < A) {
+      n = l_visit[row + lane];
+      kid = l_child[row + lane];
+      const double wsum = l_ws[row + lane];
+      const int pn = parent_n < table_len ? parent_n : table_len - 1;
+      const bool wide = root64 && node == 0;
+      const double c_pbc = pn < staged ? tab_pbc[pn] : pbc[pn];
+      const double c_sq = pn < staged ? tab_sq[pn] : sq[pn];
+      score = edge_score(c_pbc, c_sq, n, wsum, lo, hi, wide, l_prior[row + lane], wide ? root_p64 : 0.0);
+      if (!(score > ninf)) score = ninf;
+    }
+    const double best = wave_max_f64(score);
+    const unsigned long long holders = __ballot(score == best);
+    int best_a = holders ? __builtin_ctzll(holders) : 0;
+    if (parent_n >= table_len) bad = 3;
+    if (!(best > ninf)) {
+      bad = 1;
+      best_a = 0;
+    }
+    if (lane == 0) {
+      t.path_node[nbase + depth] = node;
+      t.path_action[nbase + depth] = best_a;
+    }
+    ++depth;
+    const int next = wave_uniform(__shfl(kid, best_a));
+    if (next < 0 || depth >= N) {
+      if (lane == 0) {
+        t.leaf_parent[b] = node;
+        t.leaf_action[b] = best_a;
+        t.path_len[b] = depth;
+        if (bad) t.status[b] = bad;
+      }
+      break;
+    }
+    parent_n = wave_uniform(__shfl(n, best_a));
+    node = next;
+  }
+}
+
 // ----------------------------------------------------------------- readout
 __global__ __launch_bounds__(kBlock) void readout_kernel(TreeView t, int* __restrict__ visits,
                                                         double* __restrict__ root_value,
@@ -500,6 +723,19 @@ int mz_tree_expand_backup_select(void* ws, const mz_tree_layout* L, const float*
   MZ_REQUIRE(wave >= 1, "mz_tree_expand_backup_select: wave must be >= 1 (got %d)", wave);
   MZ_REQUIRE(pbc_table && sqrt_table && table_len >= 2, "mz_tree_expand_backup_select: bad score tables");
   TreeView t = make_view(ws, L);
+  static const bool no_staging = getenv("MZ_TREE_STAGED") && atoi(getenv("MZ_TREE_STAGED")) == 0;  // kernel comparisons
+  constexpr int WPB = 4;  // one, two and four wavefronts per workgroup measured the same
+  const size_t staged_lds = 2 * kStagedTable * sizeof(double) + WPB * staged_wave_bytes(L->max_nodes, L->A);
+  if (!no_staging && L->max_nodes <= 64 && L->max_nodes * L->A <= 64 * kStagedIters && staged_lds <= 160 * 1024) {
+    static bool configured[mz::kMaxDevices] = {false};
+    auto kern = expand_backup_select_staged_kernel<WPB>;
+    if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)staged_lds, configured,
+                                        "expand_backup_select_staged"))
+      return rc;
+    hipLaunchKernelGGL(kern, dim3((L->B + WPB - 1) / WPB), dim3(WPB * 64), staged_lds, mz::as_stream(stream), t,
+                       priors, value, reward, wave, gamma, pbc_table, sqrt_table, table_len);
+    return mz::check_launch("mz_tree_expand_backup_select");
+  }
   const size_t lds = (size_t)kWavesPerBlock * 2 * L->max_nodes * sizeof(double);
   hipLaunchKernelGGL(expand_backup_select_kernel, dim3(blocks_for(L->B)), dim3(kBlock), lds, mz::as_stream(stream),
                      t, priors, value, reward, wave, gamma, pbc_table, sqrt_table, table_len);

@@ -9,14 +9,15 @@ from tests.helpers import TREE_CASES, TableNet, child_hash, load
 pytestmark = pytest.mark.gpu
 
 
-def run_device_search(g, root_hash, noise, sims, wave, record_paths=False, fused=False):
-    """fused: every descent after the first runs inside the expand+backup launch of the step before."""
+def run_device_search(g, root_hash, noise, sims, wave, record_paths=False, fused=False, slack=0):
+    """fused: every descent after the first runs inside the expand+backup launch of the step before.
+    slack: node records allocated beyond the sims // wave + 1 the search fills."""
     from muzero_amd.tree import DeviceTrees
     A = int(g["A"])
     B = len(root_hash)
     rows = g["table_priors"].shape[0]
     pri_t, val_t, rew_t = g["table_priors"], g["table_value"], g["table_reward"]
-    max_nodes = sims // wave + 1
+    max_nodes = sims // wave + 1 + slack
     trees = DeviceTrees(B, A, max_nodes, c_base=float(g["c_base"]), c_init=float(g["c_init"]),
                         max_visits=sims)
     dev = trees.device
@@ -69,6 +70,22 @@ def test_tree_kernels_match_reference_fixtures(case, fused):
             assert np.array_equal(plen, want_len)
             for b in range(len(plen)):
                 assert pact[b, :plen[b]].tolist() == g["path_act"][b, s * wave + w, :plen[b]].tolist()
+
+
+@pytest.mark.parametrize("slack", [5, 9, 30])
+def test_fused_step_with_and_without_the_lds_copy_of_the_tree(slack):
+    """The fused step keeps the game's tree in LDS when it has at most 64 nodes and 1024 edges (56 x 18 here)
+    and walks global memory otherwise (60 x 18 edges; 81 nodes): both must reproduce the fixture."""
+    g = load("g1_tree_a18_w1_noise")
+    sims, wave = int(g["sims"]), int(g["wave"])
+    trees, _ = run_device_search(g, g["root_hash"].astype(np.int64), g["noise"], sims, wave, fused=True, slack=slack)
+    visits, root_value, probs = trees.readout()
+    assert np.array_equal(visits.cpu().numpy(), g["visits"])
+    assert np.array_equal(root_value.cpu().numpy(), g["root_value"])
+    assert np.array_equal(probs.cpu().numpy(), g["probs"])
+    assert np.array_equal(trees.array("value_sum")[:, 0, :].cpu().numpy(), g["child_w"])
+    mm = trees.array("minmax").cpu().numpy()
+    assert np.array_equal(mm[:, 0], g["lo"]) and np.array_equal(mm[:, 1], g["hi"])
 
 
 @pytest.mark.parametrize("A,B,wave,fused", [(18, 1024, 1, True), (6, 256, 1, False), (9, 333, 5, True)])
