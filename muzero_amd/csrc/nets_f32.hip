@@ -97,16 +97,38 @@ struct HeadW {
   int bf16;          // w1p / w2p hold bf16 fragments for the 16x16x32 MFMA instead
 };
 
+// Sum and maximum over the 64 lanes of a wavefront, returned in every lane.  The additions form the same
+// balanced tree as a butterfly of lane exchanges at distances 1, 2, 4, ... 32 (quad permutes, half-row and row
+// mirrors pair the same groups; float addition commutes), so the sum has the butterfly's bits - at a quarter of
+// its latency: four data-parallel-primitive steps and four scalar lane reads instead of six trips through the
+// LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float readlane_f32(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror
+  v += dpp_f32<0x140>(v);  // row_mirror
+  return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+
 // softmax over the (up to 64) logits held one per lane of a wavefront
 __device__ __forceinline__ float wave_softmax(float lg, bool active) {
-  float m = active ? lg : -__builtin_inff();
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+  const float m = wave_max_f32(active ? lg : -__builtin_inff());
   const float e = active ? expf(lg - m) : 0.f;
-  float den = e;
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) den += __shfl_xor(den, k);
-  return e / den;
+  return e / wave_sum_f32(e);
 }
 
 // float32 operation sequence of inverse_transform_value (model.py:93-95);
@@ -130,19 +152,15 @@ __device__ float wave_decode_support(const float* lg, int O) {
   const int lane = threadIdx.x & 63, S = O / 2;
   float m = -__builtin_inff();
   for (int o = lane; o < O; o += 64) m = fmaxf(m, lg[o]);
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k));
+  m = wave_max_f32(m);
   float den = 0.f, num = 0.f;
   for (int o = lane; o < O; o += 64) {
     const float e = expf(lg[o] - m);
     den += e;
     num += e * (float)(o - S);
   }
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) {
-    den += __shfl_xor(den, k);
-    num += __shfl_xor(num, k);
-  }
+  den = wave_sum_f32(den);
+  num = wave_sum_f32(num);
   return inverse_value_transform(num / den);
 }
 
@@ -282,12 +300,43 @@ __device__ __forceinline__ void dense16_bf16_pre(const hbf16x8* __restrict__ wp,
   }
 }
 
+// One 16-output tile with its fragments and bias already in registers, on a bf16 image of the layer's input in
+// LDS ([16 samples][kActPitch bytes]: a lane's operand of a k-step is one 16-byte read; rounding the inputs to
+// bf16 once when they are written gives the same values as rounding them at every read, and re-reading the
+// float32 image - 64 four-byte reads per lane and tile - was what the layers spent their time on).
+constexpr int kActPitch = 256 * 2 + 16;  // bytes per sample: 33 units of 16 bytes, so 16 rows fall on 16 bank groups
+template <int KS, bool TO_BF16>
+__device__ __forceinline__ void dense16_tile(const TileFrags<KS>& fr, const float4 bv, const char* src, char* dst_act,
+                                             float* dst, int ldd, int t, bool relu) {
+  const int lane = threadIdx.x & 63;
+  const char* sp = src + (lane & 15) * kActPitch + (lane >> 4) * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr.f[ks], *reinterpret_cast<const hbf16x8*>(sp + ks * 64), acc, 0, 0, 0);
+  float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
+  if (relu) {
+    v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+  }
+  const int o = t * 16 + (lane >> 4) * 4;
+  if constexpr (TO_BF16) {
+    typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<hbf16x4*>(dst_act + (lane & 15) * kActPitch + o * 2) = hbf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+  } else {
+    float* d = dst + (lane & 15) * ldd + o;
+    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+  }
+}
+
 __device__ __forceinline__ void dense16_any(const float* wp, const float* bias, const float* src, int lds,
                                             float* dst, int ldd, int K, int tiles, bool relu) {
   if (K % 32 == 0) dense16<8>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
   else dense16<1>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
 }
 
+// FAST: every head has bf16 weights, C == Hd == 256 and at most 48 output tiles (checked by the host), so the
+// kernel holds only that path's registers.
+template <bool FAST>
 __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     const float* __restrict__ mean, int B, int C, int Hd, int A, HeadW pol, HeadW val, HeadW rew,
     float* __restrict__ priors, float* __restrict__ value, float* __restrict__ reward,
@@ -302,25 +351,56 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
   float* logit_s = mean_s;                        // [16][otiles*16+1], reuses the mean once it is consumed
   const int b0 = blockIdx.x * kHeadSamples;
   const int ns = B - b0 < kHeadSamples ? B - b0 : kHeadSamples;
-  // the reference architecture's sizes (256 -> 256 -> O) in bf16: both layers' first weight
-  // fragments are requested before the spatial means are even staged
-  const bool fast = hw.bf16 && C == 256 && Hd == 256;
-  TileFrags<8> f1;
-  if (fast && (int)(threadIdx.x >> 6) < Hd / 16)
-    load_tile_frags<8>(f1, reinterpret_cast<const hbf16x8*>(hw.w1p), threadIdx.x >> 6);
+  constexpr bool fast = FAST;
+  if constexpr (fast) {
+    // the reference architecture's sizes (256 -> 256 -> O <= 768) in bf16.  The kernel is one workgroup's chain
+    // of dependent phases, and every weight fragment comes from beyond L2 (the convolutions between two calls
+    // flush it): a wavefront requests what it will multiply as early as registers allow - its layer-1 tile and
+    // bias before the spatial means are staged, its first layer-2 tile and all biases before the barrier that
+    // publishes the means, its second layer-2 tile once the layer-1 registers are spent and its third once the
+    // first is spent.  Means and hidden layer live in LDS as bf16 images; the logits follow them as float32.
+    constexpr int NW = kHeadsBlock / 64;
+    static_assert(kHeadSamples * 256 / 4 == kHeadsBlock, "one float4 of the means per thread");
+    char* x_s = smem;
+    char* h_s = smem + kHeadSamples * kActPitch;
+    logit_s = reinterpret_cast<float*>(smem + 2 * kHeadSamples * kActPitch);
+    const int wv = threadIdx.x >> 6, lq = (threadIdx.x & 63) >> 4;
+    TileFrags<8> fa, fb;
+    const hbf16x8* w2 = reinterpret_cast<const hbf16x8*>(hw.w2p);
+    // Every load below is unconditional (sample and tile indices are clamped instead): a load inside a branch
+    // makes the compiler wait for ALL outstanding loads where the branch rejoins, and the barrier would then
+    // wait for the weight fragments too.  The means go first: loads return in order.
+    const int last = otiles - 1;
+    const int ta = wv < last ? wv : last, tb = wv + NW < last ? wv + NW : last, tc = wv + 2 * NW < last ? wv + 2 * NW : last;
+    {
+      const int s = threadIdx.x >> 6, k = (threadIdx.x & 63) * 4;
+      float4 m = *reinterpret_cast<const float4*>(mean + (long)(b0 + (s < ns ? s : ns - 1)) * 256 + k);
+      load_tile_frags<8>(fa, reinterpret_cast<const hbf16x8*>(hw.w1p), wv);
+      if (s >= ns) m = float4{0.f, 0.f, 0.f, 0.f};
+      typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<hbf16x4*>(x_s + s * kActPitch + k * 2) = hbf16x4{(__bf16)m.x, (__bf16)m.y, (__bf16)m.z, (__bf16)m.w};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 bv1 = *reinterpret_cast<const float4*>(hw.b1 + wv * 16 + lq * 4);
+    load_tile_frags<8>(fb, w2, ta);
+    const float4 bv2a = *reinterpret_cast<const float4*>(hw.b2 + ta * 16 + lq * 4);
+    const float4 bv2b = *reinterpret_cast<const float4*>(hw.b2 + tb * 16 + lq * 4);
+    const float4 bv2c = *reinterpret_cast<const float4*>(hw.b2 + tc * 16 + lq * 4);
+    __syncthreads();
+    dense16_tile<8, true>(fa, bv1, x_s, h_s, nullptr, 0, wv, true);
+    load_tile_frags<8>(fa, w2, tb);
+    __syncthreads();
+    if (wv < otiles) dense16_tile<8, false>(fb, bv2a, h_s, nullptr, logit_s, ldo, wv, false);
+    load_tile_frags<8>(fb, w2, tc);
+    if (wv + NW < otiles) dense16_tile<8, false>(fa, bv2b, h_s, nullptr, logit_s, ldo, wv + NW, false);
+    if (wv + 2 * NW < otiles) dense16_tile<8, false>(fb, bv2c, h_s, nullptr, logit_s, ldo, wv + 2 * NW, false);
+    __syncthreads();
+  } else {
   for (int i = threadIdx.x; i < kHeadSamples * C; i += kHeadsBlock) {
     const int s = i / C, k = i % C;
     mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
   }
   __syncthreads();
-  if (fast) {
-    dense16_bf16_pre<8>(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, Hd / 16, true, f1);
-    TileFrags<8> f2;  // requested before the barrier that publishes the hidden layer
-    if ((int)(threadIdx.x >> 6) < otiles) load_tile_frags<8>(f2, reinterpret_cast<const hbf16x8*>(hw.w2p), threadIdx.x >> 6);
-    __syncthreads();
-    dense16_bf16_pre<8>(reinterpret_cast<const hbf16x8*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, otiles, false, f2);
-    __syncthreads();
-  } else {
   if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   else dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   __syncthreads();
@@ -446,10 +526,19 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
     if (h) r = HeadW{static_cast<const float*>(h->w1p), h->b1, static_cast<const float*>(h->w2p), h->b2, out, h->bf16};
     return r;
   };
-  hipLaunchKernelGGL(heads_kernel, dim3((B + kHeadSamples - 1) / kHeadSamples, reward_w ? 3 : 2),
-                     dim3(kHeadsBlock), lds, mz::as_stream(stream), mean, B, C, Hd, A, cvt(policy, A),
-                     cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits, value_logits,
-                     reward_logits);
+  bool fast = C == 256 && Hd == 256 && (O + 15) / 16 <= 3 * (kHeadsBlock / 64) &&
+              reinterpret_cast<uintptr_t>(mean) % 16 == 0;
+  for (const mz_head_weights* h : {policy, value_w, reward_w}) fast = fast && (!h || h->bf16);
+  const dim3 grid((B + kHeadSamples - 1) / kHeadSamples, reward_w ? 3 : 2);
+  const size_t fast_lds = (size_t)kHeadSamples * (2 * kActPitch + (omax + 1) * sizeof(float));
+  if (fast)
+    hipLaunchKernelGGL(heads_kernel<true>, grid, dim3(kHeadsBlock), fast_lds, mz::as_stream(stream), mean, B, C, Hd, A,
+                       cvt(policy, A), cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits,
+                       value_logits, reward_logits);
+  else
+    hipLaunchKernelGGL(heads_kernel<false>, grid, dim3(kHeadsBlock), lds, mz::as_stream(stream), mean, B, C, Hd, A,
+                       cvt(policy, A), cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits,
+                       value_logits, reward_logits);
   return mz::check_launch("mz_heads");
 }
 

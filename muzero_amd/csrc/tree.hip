@@ -356,10 +356,11 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
   const int staged = table_len < kStagedTable ? table_len : kStagedTable;
   double* tab_pbc = reinterpret_cast<double*>(smem);
   double* tab_sq = tab_pbc + kStagedTable;
-  for (int i = threadIdx.x; i < staged; i += WPB * 64) {
-    tab_pbc[i] = pbc[i];
-    tab_sq[i] = sq[i];
-  }
+  // loads below are unconditional (indices clamped): a load inside a branch makes the compiler wait for every
+  // outstanding load where the branch rejoins, which would turn one round trip into several
+  static_assert(WPB * 64 >= kStagedTable, "one table entry per thread");
+  const int ti = (int)threadIdx.x < staged ? (int)threadIdx.x : staged - 1;
+  const double my_pbc = pbc[ti], my_sq = sq[ti];
   char* mine = smem + 2 * kStagedTable * sizeof(double) + (size_t)w * staged_wave_bytes(N, A);
   double* l_ws = reinterpret_cast<double*>(mine);
   double* rwd = l_ws + (size_t)N * A;
@@ -385,11 +386,12 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
   const double plo = t.minmax[2 * bb], phi = t.minmax[2 * bb + 1];
   const bool root64 = t.root_is_f64[bb] != 0;
   const size_t nbase = (size_t)bb * N;
-  const int my_pn = lane < N ? t.path_node[nbase + lane] : 0;
-  const int my_pa = lane < N ? t.path_action[nbase + lane] : 0;
-  const double my_rew = lane < N ? t.reward[nbase + lane] : 0.0;
-  const float new_prior = lane < A ? priors[(size_t)bb * A + lane] : 0.f;
-  const double root_p64 = lane < A ? t.root_prior64[(size_t)bb * A + lane] : 0.0;
+  const int ln = lane < N ? lane : N - 1, la = lane < A ? lane : A - 1;
+  const int my_pn = t.path_node[nbase + ln];
+  const int my_pa = t.path_action[nbase + ln];
+  const double my_rew = t.reward[nbase + ln];
+  const float new_prior = priors[(size_t)bb * A + la];
+  const double root_p64 = t.root_prior64[(size_t)bb * A + la];
   if (live && (e >= N || len <= 0)) {
     if (lane == 0) t.status[b] = 2;
     live = false;
@@ -400,16 +402,19 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
   int r_visit[kStagedIters], r_child[kStagedIters];
   float r_prior[kStagedIters];
   double r_ws[kStagedIters];
+  const int jmax = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
-  for (int it = 0; it < kStagedIters; ++it) {
+  for (int it = 0; it < kStagedIters; ++it) {  // no branches: records past the last one re-read it
     const int i = it * 64 + lane;
-    if (it * 64 < cnt) {
-      const int j = i < cnt ? i : cnt - 1;
-      r_visit[it] = t.visit[ebase + j];
-      r_child[it] = t.child[ebase + j];
-      r_prior[it] = t.prior[ebase + j];
-      r_ws[it] = t.value_sum[ebase + j];
-    }
+    const int j = i < jmax ? i : jmax;
+    r_visit[it] = t.visit[ebase + j];
+    r_child[it] = t.child[ebase + j];
+    r_prior[it] = t.prior[ebase + j];
+    r_ws[it] = t.value_sum[ebase + j];
+  }
+  if ((int)threadIdx.x < staged) {
+    tab_pbc[threadIdx.x] = my_pbc;
+    tab_sq[threadIdx.x] = my_sq;
   }
   if (lane < N) {
     l_pn[lane] = my_pn;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
 #pragma unroll
   for (int it = 0; it < kStagedIters; ++it) {
     const int i = it * 64 + lane;
-    if (it * 64 < cnt && i < cnt) {
+    if (i < cnt) {
       l_visit[i] = r_visit[it];
       l_child[i] = r_child[it];
       l_prior[i] = r_prior[it];
