@@ -256,10 +256,8 @@ __device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, con
   }
 }
 
-// Same layer with K = 32*KS known at compile time and the weight fragments of a whole output
-// tile requested in one go: the kernel is bound by the latency of its dependent phases, so the
-// first tile's fragments are loaded by the caller before the data they multiply exists, and the
-// next tile's travel while the current tile computes.
+// The weight fragments of a whole output tile (K = 32*KS), requested in one go: the kernel is bound by the
+// latency of its dependent phases, so a tile's fragments are loaded before the data they multiply exists.
 template <int KS>
 struct TileFrags {
   hbf16x8 f[KS];
@@ -269,35 +267,6 @@ __device__ __forceinline__ void load_tile_frags(TileFrags<KS>& fr, const hbf16x8
   const hbf16x8* w = wp + (long)t * KS * 64 + (threadIdx.x & 63);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) fr.f[ks] = w[ks * 64];
-}
-template <int KS>
-__device__ __forceinline__ void dense16_bf16_pre(const hbf16x8* __restrict__ wp, const float* __restrict__ bias,
-                                                 const float* src, int lds, float* dst, int ldd, int tiles,
-                                                 bool relu, TileFrags<KS> cur) {
-  constexpr int NW = kHeadsBlock / 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* sp = src + (lane & 15) * lds + (lane >> 4) * 8;
-  for (int t = wave; t < tiles; t += NW) {
-    TileFrags<KS> nxt;
-    if (t + NW < tiles) load_tile_frags<KS>(nxt, wp, t + NW);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      hbf16x8 bfrag;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bfrag[j] = (__bf16)sp[ks * 32 + j];
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.f[ks], bfrag, acc, 0, 0, 0);
-    }
-    const int o = t * 16 + (lane >> 4) * 4;
-    const float4 bv = *reinterpret_cast<const float4*>(bias + o);
-    float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
-    if (relu) {
-      v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-    }
-    float* d = dst + (lane & 15) * ldd + o;
-    d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
-    if (t + NW < tiles) cur = nxt;
-  }
 }
 
 // One 16-output tile with its fragments and bias already in registers, on a bf16 image of the layer's input in
