@@ -46,34 +46,55 @@ struct ConvArgs {
   long wsel_stride = 0;
 };
 
-template <class C>
-__device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const float* av, int cc, int iy0, int ix0,
-                                            int tid) {
+// Every load of the window is in flight before the first LDS write waits for one.  That only holds when the
+// loads sit in straight-line code: a load inside a branch (`if (inside) v = load`) makes the compiler wait for
+// ALL outstanding loads where the branch rejoins, one full round trip per unrolled round.  So pixels outside
+// the image load a clamped address and are zeroed afterwards, and the action-vector variant is chosen once.
+template <class C, bool AV>
+__device__ __forceinline__ void stage_input_impl(char* lds, const __bf16* src, const float* av, int cc, int iy0,
+                                                 int ix0, int tid) {
   constexpr int UPP = C::CINC / 8;  // 16-byte units per pixel
   constexpr int UNITS = C::IH * C::IW * UPP;
-  // every load of the window is in flight before the first LDS write waits for one
   constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
+  bf16x8 v[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    int u = tid + i * C::THREADS;
+    u = u < UNITS ? u : UNITS - 1;
+    const int pix = u / UPP, cu = u % UPP;
+    const int py = pix / C::IW, px = pix % C::IW;
+    int iy = iy0 + py, ix = ix0 + px;
+    iy = iy < 0 ? 0 : (iy < C::HIN ? iy : C::HIN - 1);
+    ix = ix < 0 ? 0 : (ix < C::WIN ? ix : C::WIN - 1);
+    v[i] = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
+  }
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
     const int u = tid + i * C::THREADS;
-    if (u >= UNITS) break;
-    const int pix = u / UPP, cu = u % UPP;
-    const int py = pix / C::IW, px = pix % C::IW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN) {
-      v = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
-      if (av) {
+    if (u < UNITS) {
+      const int pix = u / UPP, cu = u % UPP;
+      const int py = pix / C::IW, px = pix % C::IW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      bf16x8 w = v[i];
+      if constexpr (AV) {
         const float4 a0 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8);
         const float4 a1 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8 + 4);
-        v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
-        v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
-        v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
-        v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+        w[0] = (__bf16)((float)w[0] + a0.x); w[1] = (__bf16)((float)w[1] + a0.y);
+        w[2] = (__bf16)((float)w[2] + a0.z); w[3] = (__bf16)((float)w[3] + a0.w);
+        w[4] = (__bf16)((float)w[4] + a1.x); w[5] = (__bf16)((float)w[5] + a1.y);
+        w[6] = (__bf16)((float)w[6] + a1.z); w[7] = (__bf16)((float)w[7] + a1.w);
       }
+      if (!(iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN)) w = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<bf16x8*>(lds + py * C::ROWP + px * C::ROWB + cu * 16) = w;
     }
-    *reinterpret_cast<bf16x8*>(lds + py * C::ROWP + px * C::ROWB + cu * 16) = v;
   }
+}
+
+template <class C>
+__device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const float* av, int cc, int iy0, int ix0,
+                                            int tid) {
+  if (av) stage_input_impl<C, true>(lds, src, av, cc, iy0, ix0, tid);
+  else stage_input_impl<C, false>(lds, src, av, cc, iy0, ix0, tid);
 }
 
 // The same window from the rotating, tiled observation [H][W/16][D][56] (prep.hip): the patch's 17 input

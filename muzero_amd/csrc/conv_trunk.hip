@@ -39,21 +39,32 @@ template <int NW>
 __device__ __forceinline__ void stage_image(char* lds, const __bf16* src, const float* av, int wave, int lane) {
   // 72 blocks of (16 pixels x 4 channel chunks); lane = chunk*16 + pixel: global reads are
   // 64-byte runs per pixel, LDS writes are 16 consecutive slots per 16 lanes
+  // all loads first, in straight-line code (a load inside `if (av)` would be waited for where the branch
+  // rejoins, one round trip per round); without an action vector the additions are skipped, not the loop
   const int pl = lane & 15, qq = lane >> 4;
+  bf16x8 v[72 / NW];
+#pragma unroll
+  for (int j = 0; j < 72 / NW; ++j) {
+    const int it = wave + NW * j;
+    v[j] = *reinterpret_cast<const bf16x8*>(src + ((it >> 3) * 16 + pl) * kCh + ((it & 7) * 4 + qq) * 8);
+  }
+  if (av) {
+#pragma unroll
+    for (int j = 0; j < 72 / NW; ++j) {
+      const int q = ((wave + NW * j) & 7) * 4 + qq;
+      const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+      const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+      v[j][0] = (__bf16)((float)v[j][0] + a0.x); v[j][1] = (__bf16)((float)v[j][1] + a0.y);
+      v[j][2] = (__bf16)((float)v[j][2] + a0.z); v[j][3] = (__bf16)((float)v[j][3] + a0.w);
+      v[j][4] = (__bf16)((float)v[j][4] + a1.x); v[j][5] = (__bf16)((float)v[j][5] + a1.y);
+      v[j][6] = (__bf16)((float)v[j][6] + a1.z); v[j][7] = (__bf16)((float)v[j][7] + a1.w);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 72 / NW; ++j) {
     const int it = wave + NW * j;
     const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
-    if (av) {
-      const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
-      const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-      v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
-      v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
-      v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
-      v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
-    }
-    *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v;
+    *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v[j];
   }
   // zero pixels 144..159 of every plane: 32 planes x 16 slots = 512 slots
   const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -386,21 +397,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
     wp = PF * WSTEP;
 
     {  // image -> buffer 0 (planar); 72 blocks of (16 pixels x 4 channel chunks)
+      // all loads first, in straight-line code: a load inside `if (av)` is waited for where the branch rejoins
       const int pl = lane & 15, qq = lane >> 4;
+      bf16x8 v[72 / NW];
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        v[j] = *reinterpret_cast<const bf16x8*>(src + ((it >> 3) * 16 + pl) * kCh + ((it & 7) * 4 + qq) * 8);
+      }
+      if (av) {
+#pragma unroll
+        for (int j = 0; j < 72 / NW; ++j) {
+          const int q = ((wave + NW * j) & 7) * 4 + qq;
+          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+          v[j][0] = (__bf16)((float)v[j][0] + a0.x); v[j][1] = (__bf16)((float)v[j][1] + a0.y);
+          v[j][2] = (__bf16)((float)v[j][2] + a0.z); v[j][3] = (__bf16)((float)v[j][3] + a0.w);
+          v[j][4] = (__bf16)((float)v[j][4] + a1.x); v[j][5] = (__bf16)((float)v[j][5] + a1.y);
+          v[j][6] = (__bf16)((float)v[j][6] + a1.z); v[j][7] = (__bf16)((float)v[j][7] + a1.w);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 72 / NW; ++j) {
         const int it = wave + NW * j;
         const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
-        if (av) {
-          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
-          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-          v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
-          v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
-          v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
-          v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
-        }
-        *reinterpret_cast<bf16x8*>(lds + plane_of(q) * kPlaneB + pix * 16) = v;
+        *reinterpret_cast<bf16x8*>(lds + plane_of(q) * kPlaneB + pix * 16) = v[j];
       }
     }
     __syncthreads();
@@ -623,23 +644,36 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
   auto wdesc = [&](int l) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
   };
-  auto image_base = [&](int bb) {
-    const long img = a.in_slot ? (long)a.in_slot[bb] * a.slot_stride + bb : bb;
-    return a.in + img * (long)(kPix * kCh);
-  };
+  // Loads in this kernel are unconditional, with a valid stand-in address where the real one does not apply: a
+  // load inside a branch makes the compiler wait for every outstanding load where the branch rejoins, which
+  // turned the 18 loads of a pass's images (and the bookkeeping before them) into as many round trips.
+  const int* const slot_p = a.in_slot ? a.in_slot : reinterpret_cast<const int*>(a.bias[0]);
+  const int* const act_p = a.avec ? a.actions : reinterpret_cast<const int*>(a.bias[0]);
   const int pl = lane & 15, qq = lane >> 4;
 
-  int touched = 0;  // sink of the next-pair prefetch loads (keeps them alive; never stored)
   for (int b0 = blockIdx.x; b0 < a.B; b0 += 2 * gridDim.x) {
-    // the pass's images; a missing second image repeats the first and is never stored
+    // the pass's images (a missing second image repeats the first and is never stored) and the next pass's,
+    // which are pulled towards L2 during the last layer (a missing one repeats this pass's first)
     const bool two = b0 + (int)gridDim.x < a.B;
-    const int bimg[2] = {b0, two ? b0 + (int)gridDim.x : b0};
-    // next pass's images, pulled towards L2 during the last layer (one 4-byte load per 128-byte line)
-    const char* nsrc[2] = {nullptr, nullptr};
+    int bsel[4] = {b0, two ? b0 + (int)gridDim.x : b0, b0, b0};
+#pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int nb = b0 + (2 + i) * (int)gridDim.x;
-      if (nb < a.B) nsrc[i] = reinterpret_cast<const char*>(image_base(nb));
+      if (nb < a.B) bsel[2 + i] = nb;
     }
+    const int bimg[2] = {bsel[0], bsel[1]};
+    int slot[4], act[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slot[i] = slot_p[a.in_slot ? bsel[i] : 0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) act[i] = act_p[a.avec ? bimg[i] : 0];
+    const __bf16* isrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long img = a.in_slot ? (long)__builtin_amdgcn_readfirstlane(slot[i]) * a.slot_stride + bsel[i] : bsel[i];
+      isrc[i] = a.in + img * (long)(kPix * kCh);
+    }
+    const char* nsrc[2] = {reinterpret_cast<const char*>(isrc[2]), reinterpret_cast<const char*>(isrc[3])};
 
     __amdgpu_buffer_rsrc_t wr = wdesc(0);
     int wp = 0;
@@ -655,24 +689,35 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
     // registers, or rather in scratch memory, through every layer of every pass)
     int plv = pl, qqv = qq;
     asm volatile("" : "+v"(plv), "+v"(qqv));
+    {  // images -> LDS (planar); 72 blocks of (16 pixels x 4 channel chunks) each.  A lane's channel chunk is the
+       // same in all nine rounds (eight wavefronts: block it = wave + 8 j), so one pair of action-vector loads
+       // per image serves them all; all 18 image loads and the 4 vector loads travel together.
+      static_assert(NW == 8, "a lane's channel chunk must not depend on the round");
+      const int q = wave * 4 + qqv;
+      bf16x8 v[2][72 / NW];
+      float4 a0[2], a1[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {  // images -> LDS (planar); 72 blocks of (16 pixels x 4 channel chunks) each
-      const __bf16* src = image_base(bimg[i]);
-      const float* av = a.avec ? a.avec + (long)a.actions[bimg[i]] * kCh : nullptr;
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int j = 0; j < 72 / NW; ++j) {
-        const int it = wave + NW * j;
-        const int pix = (it >> 3) * 16 + plv, q = (it & 7) * 4 + qqv;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
-        if (av) {
-          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
-          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-          v[0] = (__bf16)((float)v[0] + a0.x); v[1] = (__bf16)((float)v[1] + a0.y);
-          v[2] = (__bf16)((float)v[2] + a0.z); v[3] = (__bf16)((float)v[3] + a0.w);
-          v[4] = (__bf16)((float)v[4] + a1.x); v[5] = (__bf16)((float)v[5] + a1.y);
-          v[6] = (__bf16)((float)v[6] + a1.z); v[7] = (__bf16)((float)v[7] + a1.w);
+        for (int j = 0; j < 72 / NW; ++j)
+          v[i][j] = *reinterpret_cast<const bf16x8*>(isrc[i] + (j * 16 + plv) * kCh + q * 8);
+        const float* av = a.avec ? a.avec + (long)__builtin_amdgcn_readfirstlane(act[i]) * kCh : a.bias[0];
+        a0[i] = *reinterpret_cast<const float4*>(av + q * 8);
+        a1[i] = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 72 / NW; ++j) {
+          bf16x8 w = v[i][j];
+          if (a.avec) {
+            w[0] = (__bf16)((float)w[0] + a0[i].x); w[1] = (__bf16)((float)w[1] + a0[i].y);
+            w[2] = (__bf16)((float)w[2] + a0[i].z); w[3] = (__bf16)((float)w[3] + a0[i].w);
+            w[4] = (__bf16)((float)w[4] + a1[i].x); w[5] = (__bf16)((float)w[5] + a1[i].y);
+            w[6] = (__bf16)((float)w[6] + a1[i].z); w[7] = (__bf16)((float)w[7] + a1[i].w);
+          }
+          *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + (j * 16 + plv) * 16) = w;
         }
-        *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + pix * 16) = v;
       }
     }
     __syncthreads();
@@ -701,14 +746,14 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
 #pragma unroll
       for (int mt = 0; mt < kMT; ++mt) af[mt] = *(lds_frag_ptr)(aaddr[mt]);
 
-      int pf = 0;
-      if (last) {  // 2 x 576 lines of 128 bytes, 512 threads
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          if (nsrc[i]) {
-            pf ^= *reinterpret_cast<const int*>(nsrc[i] + tid * 128);
-            if (tid < kPix * kCh * 2 / 128 - 64 * NW) pf ^= *reinterpret_cast<const int*>(nsrc[i] + (64 * NW + tid) * 128);
-          }
+      if (last) {  // 2 x 576 lines of 128 bytes: line tid of each image, the 64 tail lines of both images by
+                   // wavefronts 0 and 1 (the others repeat theirs).  One register: holding three through the
+                   // main loop so that nothing waits here costs more (+2 % per launch) than the wait.
+        static_assert(kPix * kCh * 2 / 128 == 64 * NW + 64, "512 lines + 64");
+        int pf = *reinterpret_cast<const int*>(nsrc[0] + tid * 128);
+        pf ^= *reinterpret_cast<const int*>(nsrc[1] + tid * 128);
+        pf ^= *reinterpret_cast<const int*>(nsrc[wave & 1] + (64 * NW + lane) * 128);
+        asm volatile("" ::"v"(pf));  // keeps the loads alive
       }
 
 #pragma unroll 1
@@ -757,7 +802,6 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
           }
         }
       }
-      touched ^= pf;
       MZ_STAMP(1);  // main loop done
 
       float4 bv[WN];  // requested before the barrier, needed after it
@@ -836,7 +880,6 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
     }
     __syncthreads();  // the next images overwrite these
   }
-  if (a.B < 0) a.mean_out[tid] = __int_as_float(touched);  // never true: B > 0 is checked by the host
 }
 
 template <int NW, int PF, int SPLIT>
