@@ -40,17 +40,28 @@ __device__ __forceinline__ void stage_window(char* lds, const __bf16* src, int c
   constexpr int UPP = C::CINC / 8;
   constexpr int UNITS = C::IH * C::IW * UPP;
   constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
+  // loads in straight-line code (clamped address, zeroed afterwards): a load inside a branch is waited for
+  // where the branch rejoins, one round trip per round
+  bf16x8 v[ROUNDS];
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    int u = tid + i * C::THREADS;
+    u = u < UNITS ? u : UNITS - 1;
+    const int pix = u / UPP, cu = u % UPP;
+    int iy = iy0 + pix / C::IW, ix = ix0 + pix % C::IW;
+    iy = iy < 0 ? 0 : (iy < C::HIN ? iy : C::HIN - 1);
+    ix = ix < 0 ? 0 : (ix < C::WIN ? ix : C::WIN - 1);
+    v[i] = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
+  }
 #pragma unroll
   for (int i = 0; i < ROUNDS; ++i) {
     const int u = tid + i * C::THREADS;
-    if (u >= UNITS) break;
-    const int pix = u / UPP, cu = u % UPP;
-    const int py = pix / C::IW, px = pix % C::IW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN)
-      v = *reinterpret_cast<const bf16x8*>(src + ((long)iy * C::WIN + ix) * C::CIN + cc * C::CINC + cu * 8);
-    *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = v;
+    if (u < UNITS) {
+      const int pix = u / UPP, cu = u % UPP;
+      const int iy = iy0 + pix / C::IW, ix = ix0 + pix % C::IW;
+      const bool inside = iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN;
+      *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = inside ? v[i] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
   }
 }
 
@@ -303,25 +314,38 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
     }
     int wp = WSTEP;
 
+    {  // both components -> LDS (planar); the action vector is added in float32.  All loads first, in
+       // straight-line code: a load inside `if (av)` is waited for where the branch rejoins, once per round
+      bf16x8 vh[72 / NW], vl[72 / NW];
 #pragma unroll
-    for (int j = 0; j < 72 / NW; ++j) {  // both components -> LDS (planar); the action vector is added in float32
-      const int it = wave + NW * j;
-      const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
-      bf16x8 vh = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
-      bf16x8 vl = *reinterpret_cast<const bf16x8*>(src + IMG + pix * kCh + q * 8);
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        vh[j] = *reinterpret_cast<const bf16x8*>(src + pix * kCh + q * 8);
+        vl[j] = *reinterpret_cast<const bf16x8*>(src + IMG + pix * kCh + q * 8);
+      }
       if (av) {
-        const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
-        const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-        const float add[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = ((float)vh[e] + (float)vl[e]) + add[e];
-          vh[e] = (__bf16)v;
-          vl[e] = (__bf16)(v - (float)vh[e]);
+        for (int j = 0; j < 72 / NW; ++j) {
+          const int q = ((wave + NW * j) & 7) * 4 + qq;
+          const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
+          const float add[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = ((float)vh[j][e] + (float)vl[j][e]) + add[e];
+            vh[j][e] = (__bf16)v;
+            vl[j][e] = (__bf16)(v - (float)vh[j][e]);
+          }
         }
       }
-      *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2) * kPlaneB + pix * 16) = vh;
-      *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + 1) * kPlaneB + pix * 16) = vl;
+#pragma unroll
+      for (int j = 0; j < 72 / NW; ++j) {
+        const int it = wave + NW * j;
+        const int pix = (it >> 3) * 16 + pl, q = (it & 7) * 4 + qq;
+        *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2) * kPlaneB + pix * 16) = vh[j];
+        *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + 1) * kPlaneB + pix * 16) = vl[j];
+      }
     }
     __syncthreads();
 
