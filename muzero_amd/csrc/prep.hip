@@ -139,12 +139,21 @@ __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char
   if (fill_mask && fill_mask[b]) fill_all = 1;  // this game starts a new episode
   const unsigned char* f = frames + ((long)b * HW + (long)t * 16) * 3 - 3;  // byte e of the run's 51 values
   const bool first_in_row = (t % (W / 16)) == 0;
+  // the unit's bytes are loaded unconditionally (halo of a row's first tile and padding read a clamped, valid
+  // byte and are zeroed afterwards): a load inside a branch is waited for before the next one is requested
+  unsigned char raw[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    int e = u * V + j;
+    e = e < 50 ? e : 50;
+    e = first_in_row && e < 3 ? 3 : e;
+    raw[j] = f[e];
+  }
   OutT v[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     const int e = u * V + j;
-    float x = 0.f;
-    if (e < 51 && !(first_in_row && e < 3)) x = (float)f[e] / 255.0f;
+    const float x = (e < 51 && !(first_in_row && e < 3)) ? (float)raw[j] / 255.0f : 0.f;
     if constexpr (sizeof(OutT) == 2) v[j] = f32_to_bf16_rne(x);
     else v[j] = x;
   }
