@@ -157,3 +157,35 @@ def test_full_size_search_properties_and_sampled_replay(A, B, precision):
     m.check_status()
     assert np.array_equal(res.visit_counts.cpu().numpy(), visits)
     assert np.array_equal(res.root_values.cpu().numpy(), values)
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 333, 1024])
+def test_bf16_heads_match_their_arithmetic_in_torch(B):
+    """The heads on bf16 weights and bf16-rounded inputs with float32 accumulation, restated in torch (the spatial
+    means and the hidden layer rounded to bf16 exactly where the kernel rounds them).  Only the order of the
+    float32 partial sums differs - and with it, now and then, the bf16 rounding of a hidden unit that sits on a
+    rounding boundary (one flip moves a logit by ~3e-4): logits to 2e-3, priors to 1e-5 of the softmax of the
+    kernel's own logits, decoded scalars to 1e-3 relative / 2e-3 absolute of the decode of the kernel's own logits
+    (the decode itself is pinned bit for bit by the fixture test in test_nets_gpu.py).
+    Batch sizes that leave the last workgroup's 16 samples partly or wholly empty included."""
+    from oracle import nets as onets
+    cfg, ref, net = _nets(18)
+    torch.manual_seed(B)
+    mean = (torch.randn(B, 256, device="cuda") * 0.5).contiguous()
+    priors, value, reward, pl, vl, rl = net._heads(mean, B, True, True)
+    torch.cuda.synchronize()
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+
+    def mlp(seq, x):
+        l1, l2 = seq[0], seq[2]
+        h = torch.relu(rb(x) @ rb(l1.weight.detach().cuda()).T + l1.bias.detach().cuda())
+        return rb(h) @ rb(l2.weight.detach().cuda()).T + l2.bias.detach().cuda()
+
+    for got, seq in ((pl, ref.prediction.policy_head), (vl, ref.prediction.value_head), (rl, ref.dynamics.reward_head)):
+        want = mlp(seq, mean)
+        rms = float(want.pow(2).mean().sqrt())
+        assert float((got - want).abs().max()) <= 2e-3 * max(rms, 1.0), (float((got - want).abs().max()), rms)
+    assert float((priors - torch.softmax(pl, 1)).abs().max()) <= 1e-5
+    for got, lg in ((value, vl), (reward, rl)):
+        want = onets.decode_support(lg.cpu(), cfg.support_size).view(-1)
+        assert torch.allclose(got.cpu(), want, rtol=1e-3, atol=2e-3)  # float32 cancellation near zero
