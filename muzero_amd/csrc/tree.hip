@@ -189,7 +189,7 @@ __device__ __forceinline__ void select_game(const TreeView& t, const double* __r
       t.path_action[(size_t)b * t.N + depth] = best_a;
     }
     ++depth;
-    const int next = wave_uniform(__shfl(kid, best_a));
+    const int next = __builtin_amdgcn_readlane(kid, best_a);  // best_a is wave-uniform: a scalar lane read, no LDS trip
     if (next < 0 || depth >= t.N) {
       if (lane == 0) {
         t.leaf_parent[b] = node;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void select_game(const TreeView& t, const double* __r
       }
       break;
     }
-    parent_n = wave_uniform(__shfl(n, best_a));
+    parent_n = __builtin_amdgcn_readlane(n, best_a);
     node = next;
   }
 }
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
       t.path_action[nbase + depth] = best_a;
     }
     ++depth;
-    const int next = wave_uniform(__shfl(kid, best_a));
+    const int next = __builtin_amdgcn_readlane(kid, best_a);  // best_a is wave-uniform: a scalar lane read, no LDS trip
     if (next < 0 || depth >= N) {
       if (lane == 0) {
         t.leaf_parent[b] = node;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WPB * 64) void expand_backup_select_staged_kernel(
       }
       break;
     }
-    parent_n = wave_uniform(__shfl(n, best_a));
+    parent_n = __builtin_amdgcn_readlane(n, best_a);
     node = next;
   }
 }
