@@ -159,7 +159,9 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
       if (last && nsrc) {  // 1152 lines of 128 bytes, 512 threads: pull the next image towards L2
         pf ^= *reinterpret_cast<const int*>(nsrc + tid * 128);
         pf ^= *reinterpret_cast<const int*>(nsrc + (512 + tid) * 128);
-        if (tid < mPix * mCh * 2 / 128 - 1024) pf ^= *reinterpret_cast<const int*>(nsrc + (1024 + tid) * 128);
+        // unconditional (threads past the last line repeat it): a guarded load would be waited for on its own
+        constexpr int kLines = mPix * mCh * 2 / 128;
+        pf ^= *reinterpret_cast<const int*>(nsrc + (1024 + tid < kLines ? 1024 + tid : kLines - 1) * 128);
       }
 
 #pragma unroll 1
