@@ -9,6 +9,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Sum over the 16 lanes of a row (lanes with the same lane >> 4), returned in each of them: quad permutes and row
+// mirrors pair the same groups of lanes as a butterfly of exchanges at distances 1, 2, 4, 8 would - the same tree
+// of additions, the same bits - without four trips through the LDS crossbar.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));  // row_mirror
+  return v;
+}
+
 #ifndef MZ_ROWPAD
 #define MZ_ROWPAD 1
 #endif

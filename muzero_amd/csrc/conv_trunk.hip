@@ -246,10 +246,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
       }
     }
     if (a.mean_out) {
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
-      }
+      s0 = row16_sum(s0); s1 = row16_sum(s1); s2 = row16_sum(s2); s3 = row16_sum(s3);
       if (r16 == 0) {
         const float inv = 1.0f / (float)kPix;
         *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) = make_float4(s0 * inv, s1 * inv, s2 * inv, s3 * inv);
@@ -547,10 +544,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
             *reinterpret_cast<bf16x4*>(slot) = ov;
           }
           if (kMean) {
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-              s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
-            }
+            s0 = row16_sum(s0); s1 = row16_sum(s1); s2 = row16_sum(s2); s3 = row16_sum(s3);
             if (r16 == 0) {
               const float inv = 1.0f / (float)kPix;
               *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
@@ -849,10 +843,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
             *reinterpret_cast<bf16x4*>(slot) = ov;
           }
           if (want_mean) {  // only the last layer's outputs are averaged over the pixels (the heads' input)
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) {
-              s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
-            }
+            s0 = row16_sum(s0); s1 = row16_sum(s1); s2 = row16_sum(s2); s3 = row16_sum(s3);
             if (r16 == 0 && (i == 0 || two)) {
               const float inv = 1.0f / (float)kPix;
               *reinterpret_cast<float4*>(a.mean_out + (long)bimg[i] * kCh + cbase) =

@@ -469,10 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
           *reinterpret_cast<bf16x4*>(slot + kPlaneB) = lo;
         }
         if (want_mean) {
-#pragma unroll
-          for (int m = 1; m < 16; m <<= 1) {
-            s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); s3 += __shfl_xor(s3, m);
-          }
+          s0 = row16_sum(s0); s1 = row16_sum(s1); s2 = row16_sum(s2); s3 = row16_sum(s3);
           if (r16 == 0) {
             const float inv = 1.0f / (float)kPix;
             *reinterpret_cast<float4*>(a.mean_out + (long)b * kCh + cbase) =
