@@ -215,11 +215,15 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
       __syncthreads();  // every wavefront has read the layer's input: it may be overwritten
       const bool relu = (a.relu_mask >> l) & 1u;
       const bool keep_input = !last && ((a.res_mask >> (l + 1)) & 1u);  // the next layer adds this layer's input
-      if (!last) {  // next layer's first weight fragments travel while the epilogue runs
+      {  // next layer's first weight fragments travel while the epilogue runs; not guarded by `!last` (the last
+         // layer requests its own first fragments again, unused): loads in a branch cannot be counted, and the
+         // epilogue's first use of the bias would wait for them too.  The empty asm looks at the biases here.
         wr = wr_next;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) wq[nt] = wfrag(wr, 0, nt);
         wp = mWStep;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) asm volatile("" ::"v"(bv[nt].x));
       }
       // epilogue: a lane holds channels cbase..cbase+3 (half a 16-byte chunk) of pixel (tile * 16 + r16);
       // results replace the layer's input in place

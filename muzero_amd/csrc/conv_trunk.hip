@@ -512,7 +512,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       MZ_STAMP(1);  // main loop done
       // next layer's first weight fragments travel while this layer's epilogue runs
       const bool relu = (a.relu_mask >> l) & 1u;
-      if (!last) {
+      {  // not guarded by `!last` (the last layer requests its own first fragments again, unused): loads in a
+         // branch cannot be counted, so a later wait for anything older would wait for them too
         wr = wr_next;
 #pragma unroll
         for (int p = 0; p < PF; ++p)
@@ -806,13 +807,18 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       MZ_STAMP(2);  // everyone has finished reading
       const bool relu = (a.relu_mask >> l) & 1u;
       const bool keep_input = !last && ((a.res_mask >> (l + 1)) & 1u);  // the next layer adds this layer's input
-      if (!last) {  // next layer's first weight fragments travel while the epilogue runs
+      {  // next layer's first weight fragments travel while the epilogue runs.  Not guarded by `!last` (the last
+         // layer requests its own first fragments again, unused): with the loads in a branch the compiler cannot
+         // count them and the epilogue's first use of the bias would wait for these loads too, a round trip to
+         // L2 at the start of every epilogue.  The empty asm looks at the biases here, where the count is known.
         wr = wr_next;
 #pragma unroll
         for (int p = 0; p < PF; ++p)
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) wq[p][nt] = wfrag(wr, p * WSTEP, nt);
         wp = PF * WSTEP;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) asm volatile("" ::"v"(bv[nt].x));
       }
       // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
       // mt*16 + r16 of both images; results replace the layer's input in place

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
       __syncthreads();  // every wavefront has read the layer's input: it may be overwritten
       const bool relu = (a.relu_mask >> l) & 1u;
       const bool keep_input = !last && ((a.res_mask >> (l + 1)) & 1u);  // the next layer adds this layer's input
-      if (!last) {
+      {  // not guarded by `!last` (the last layer requests its own first fragments again, unused): loads in a
+         // branch cannot be counted, and the epilogue's first use of the bias would wait for them too
         wrh = wrh_next;
         wrl = wrl_next;
 #pragma unroll
@@ -439,6 +440,8 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
           wl[nt] = wfrag(wrl, 0, nt);
         }
         wp = WSTEP;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) asm volatile("" ::"v"(bv[nt].x));
       }
       const float floor_v = relu ? 0.f : -__builtin_inff();
       const bool want_mean = last && a.mean_out;
