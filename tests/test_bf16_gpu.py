@@ -21,11 +21,13 @@ def _nets(A, precision="bf16"):
     return cfg, ref, MuZeroNetwork(cfg, precision=precision, state_dict=ref.state_dict())
 
 
-def test_bf16_network_close_to_reference_fixture():
-    """bf16 activations and weights, fp32 accumulation: the bound stated here is
-    2% of each output tensor's RMS (measured ~0.5%); hidden states 3% of RMS."""
+@pytest.mark.parametrize("A", [6, 18])
+def test_bf16_network_close_to_reference_fixture(A):
+    """bf16 activations and weights, fp32 accumulation, against the reference's float32 outputs (g3) at both
+    fixture action counts - 18 is the benchmark's.  The bound stated for this precision: the largest error of
+    an output tensor at most 2 % of that tensor's RMS (hidden states 6 %); the measured ratios are printed."""
+    from muzero_amd.network import support_to_scalar
     from muzero_amd.prep import prepare_observation
-    A = 6
     g = load("g3_nets_full")
     cfg, ref, net = _nets(A)
     frames = np.random.default_rng(1234).integers(0, 256, size=(2, 96, 96, 96), dtype=np.uint8)
@@ -33,16 +35,23 @@ def test_bf16_network_close_to_reference_fixture():
     act = torch.tensor([[1], [A - 1]])
     o0 = net.initial_inference(obs)
     o1 = net.recurrent_inference(o0.hidden_state, act)
+    o2 = net.recurrent_inference(o1.hidden_state, act.flip(0))
     torch.cuda.synchronize()
+    report = {}
 
     def close(got, key, frac):
         want = g[f"A{A}_{key}"]
         rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
         err = float(np.abs(got.cpu().numpy() - want).max())
+        report[key] = round(err / max(rms, 1e-3), 4)
         assert err <= frac * max(rms, 1e-3), (key, err, rms)
     close(o0.hidden_state[:1], "h0", 0.06); close(o0.policy_logits, "p0", 0.02); close(o0.value, "v0", 0.02)
     close(o1.hidden_state[:1], "h1", 0.06); close(o1.policy_logits, "p1", 0.02)
     close(o1.value, "v1", 0.02); close(o1.reward, "r1", 0.02)
+    close(o2.policy_logits, "p2", 0.02); close(o2.value, "v2", 0.02); close(o2.reward, "r2", 0.02)
+    close(support_to_scalar(o0.value, 300), "sv0", 0.02); close(support_to_scalar(o1.value, 300), "sv1", 0.02)
+    close(support_to_scalar(o1.reward, 300), "sr1", 0.02)
+    print(f"bf16 vs reference fixture, A={A}: max error / RMS per output", report)
 
 
 @pytest.mark.parametrize("A,B,wave", [(18, 16, 1), (6, 9, 5)])
@@ -114,26 +123,46 @@ def test_selfplay_worker_evaluate_mode_and_temperature_zero():
 
 @pytest.mark.parametrize("A,B,precision", [(6, 256, "bf16"), (18, 1024, "bf16"), (9, 4096, "bf16"), (18, 1024, "bf16x3")])
 def test_full_size_search_properties_and_sampled_replay(A, B, precision):
-    """The benchmark configurations at their full sizes: size-independent properties for every game
-    (visit counts sum to the simulation count, one node per simulation, no status flags), the
-    oracle tree replaying the recorded network outputs bit-exactly for a sample of games, and the
-    production one-call search giving the same result as the stepwise one."""
+    """The benchmark configurations at their full sizes, through the calls the benchmark makes (for bf16 the
+    ROTATING observation and the first convolution's permuted weight copies, after enough moves to wrap the ring):
+    size-independent properties for every game (visit counts sum to the simulation count, one node per simulation,
+    no status flags), the oracle tree replaying the recorded network outputs bit-exactly for a sample of games,
+    the root priors of a few games against the CPU oracle networks, and SelfPlayWorker.step() giving the same
+    result as the stepwise search."""
     from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    from oracle import prep as oprep
     from oracle import tree as otree
     cfg, ref, net = _nets(A, precision)
     sims = 50
     worker = SelfPlayWorker(cfg, net, B, sims, 1)
-    env = SyntheticEnv(B, device="cuda", pool=2)
+    assert worker.rotating == (precision == "bf16")
+    env = SyntheticEnv(B, device="cuda", pool=3)
     worker.reset(env.reset())
-    worker.ring.push(env.step())
+    for _ in range(34):                       # past the ring's wrap: newest slot 1
+        worker.ring.push(env.step())
     worker.draw_randomness()
     m = worker.mcts
     rng = np.random.default_rng(B)
     sample = rng.choice(B, size=24, replace=False)
     idx = torch.from_numpy(sample).cuda()
-    obs = worker.ring.observation(net.obs_dtype, out=worker.obs, pairs=worker.pairs)
-    pri0, _ = net.initial_to_pool(obs, m.pool[0])
+    if worker.rotating:
+        obs, newest = worker.ring.rotating_observation()
+        assert newest == 1
+    else:
+        obs, newest = worker.ring.observation(net.obs_dtype, out=worker.obs, pairs=worker.pairs), None
+    pri0, val0 = net.initial_to_pool(obs, m.pool[0], newest)
     p0 = pri0[idx].cpu().numpy()
+    # root priors / values of four sampled games against the float32 CPU networks on the stacked observation
+    # rebuilt from the synthetic frames on the host (reset frame 0, then frames t % 3 for t = 1..34)
+    few = sample[:4]
+    host = env.host.numpy()
+    stack = [host[t % 3][few] for t in range(3, 35)]                      # the last 32 pushes, oldest first
+    stacked = np.concatenate(stack, axis=-1)
+    with torch.no_grad():
+        _, p_ref, v_ref = ref.initial(torch.tensor(oprep.prepare(stacked)))
+    want = torch.softmax(p_ref, dim=1).numpy()
+    tol = 0.02 if precision == "bf16" else 1e-3
+    assert np.abs(p0[:4] - want).max() <= tol * want.max(), np.abs(p0[:4] - want).max()
     m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)
     m.trees.select()
     log = []
@@ -153,10 +182,16 @@ def test_full_size_search_properties_and_sampled_replay(A, B, precision):
         root, _ = otree.search(p0[j], None, lambda h, a, it=it: [next(it)] * len(a), sims, 1, noise=noise[b])
         assert otree.visit_counts(root).tolist() == visits[b].tolist()
         assert root.q() == values[b]
-    res = m.run(obs, worker.noise)
+    res = m.run(obs, worker.noise, rotation=newest)
     m.check_status()
     assert np.array_equal(res.visit_counts.cpu().numpy(), visits)
     assert np.array_equal(res.root_values.cpu().numpy(), values)
+    # the benchmark's own call: no new frame, same noise -> the same search
+    actions, res = worker.step(None, temperature=1.0, add_noise=True)
+    assert np.array_equal(res.visit_counts.cpu().numpy(), visits)
+    assert np.array_equal(res.root_values.cpu().numpy(), values)
+    a = actions.cpu().numpy()
+    assert (visits[np.arange(B), a] > 0).all()
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 333, 1024])
