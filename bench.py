@@ -7,8 +7,12 @@ game into the device frame ring and the stacked observation, run the search
 inference) and choose an action per game.  Synthetic frames and weights.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rehearsal of the N-rank path on ONE GPU (every rank on device 0, rendezvous and collectives on gloo because
+RCCL wants one GPU per rank):  MZ_FORCE_DEVICE=0 MZ_DIST_BACKEND=gloo python bench.py --gpus 2 --batch 256
 
 Games are sharded over ranks with no data-path collective (weak scaling: the
 per-GPU batch is fixed); RCCL only broadcasts the weights before the timed region.
@@ -17,6 +21,8 @@ Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -194,6 +200,42 @@ def chain_roofline(wl, precision, traffic=None):
     return out, tree_s, heads_s
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` copies of this script as ranks 0..n-1 of one job (one per GPU) and wait for them: what
+    `torch.distributed.run --nproc-per-node n` would do, for a caller that just runs `bench.py --gpus n`.
+    Called before anything in this process touches a GPU.  Rank 0 inherits stdout, so its JSON line is this
+    process's output; the first rank to fail ends the others.  Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    code = 0
+    live = dict(enumerate(procs))
+    while live and code == 0:
+        for r, p in list(live.items()):
+            rc = p.poll()
+            if rc is not None:
+                del live[r]
+                if rc != 0:
+                    print(f"bench.py: rank {r} exited with code {rc}", file=sys.stderr)
+                    code = rc if rc > 0 else 1
+        time.sleep(0.05)
+    for p in live.values():            # a rank failed: the others would wait for it in a collective for ever
+        p.terminate()
+    for p in live.values():
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,9 +263,13 @@ def main():
     from muzero_amd.config import MuZeroConfig
     from muzero_amd.network import init_state_dict
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     rank, world, local = mzdist.init_from_env("gloo" if args.dry else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MZ_BENCH_FAIL_RANK") == str(rank):     # test hook: this rank dies after the rendezvous
+        os._exit(3)
     A, B, label = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
@@ -244,6 +290,7 @@ def main():
     sd = mzdist.broadcast_state_dict(sd, src=0)
     if not mzdist.verify_same_everywhere(sd):
         raise SystemExit("weight broadcast left ranks with different parameters")
+    digests = mzdist.gather_checksums(sd) if world > 1 else None     # every rank's digest, reported by rank 0
 
     if args.dry:
         barrier()
@@ -257,6 +304,7 @@ def main():
             print(json.dumps({"metric": "mcts_sims_per_sec", "value": None, "unit": "sims/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry": True,
                               "elapsed_max_over_ranks_s": elapsed, "scaling": "weak",
+                              "weights_sha256_per_rank": digests,
                               "config": {"workload": desc, "games_per_gpu": B, "parallelism": f"games sharded x{world}"}}))
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -286,6 +334,9 @@ def main():
             "env_frames_per_sec": 4 * world * B * args.steps / elapsed,
             "visit_sum_check": True,
         }
+        if digests is not None:
+            out["weights_sha256_per_rank"] = digests
+            out["collective_backend"] = torch.distributed.get_backend()
         prof = load_profiled_traffic()
         traffic = None
         if prof and prof.get("games_per_gpu") == B and args.precision == "bf16":

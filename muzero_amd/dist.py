@@ -132,13 +132,21 @@ def broadcast_state_dict(sd, src: int = 0, device=None):
     return OrderedDict((k, out[k]) for k in sd)
 
 
+def gather_checksums(sd) -> list:
+    """SHA-256 of the state_dict on every rank, in rank order (one all-gather of the digests)."""
+    digest = state_checksum(sd)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [digest]
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, digest)
+    return gathered
+
+
 def verify_same_everywhere(sd) -> bool:
     """True when every rank holds bit-identical parameters (checksum all-gather)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return True
-    digest = state_checksum(sd)
-    gathered = [None] * dist.get_world_size()
-    dist.all_gather_object(gathered, digest)
+    gathered = gather_checksums(sd)
     return all(g == gathered[0] for g in gathered)
 
 
