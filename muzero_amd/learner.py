@@ -1012,10 +1012,13 @@ class Learner:
     # ---- the whole update as one HIP graph
     def update_graphed(self, observations, actions, target_values, target_rewards, target_policies, weights):
         """``update_from_tensors`` replayed from a HIP graph: losses, backward pass, gradient clipping and the
-        SGD step of one batch shape are recorded once (after three eager warm-up updates on that shape)
-        and then replayed - an eager update is ~2000 kernel launches and bound by the host that issues them.
-        The graph is recorded again when the batch shape or the learning rate changes.  Returns the same
-        dictionary; the metrics are read back after the replay."""
+        SGD step of one batch shape are recorded once and then replayed - an eager update is ~2000 kernel
+        launches and bound by the host that issues them.  Recording needs three eager passes first
+        (allocations, solver choices, momentum buffers); they run on the caller's batch, and everything they
+        change - parameters, BatchNorm statistics and counters, momentum - is put back before the recording, so
+        that every call, the first included, is exactly ONE update per batch as train.py:303-313 (neither the
+        schedule nor ``training_step`` moves during the warm-up).  The graph is recorded again when the batch shape
+        or the learning rate changes.  Returns the same dictionary; the metrics are read back after the replay."""
         if self.data_parallel:
             raise NotImplementedError("the graphed update does not include the gradient all-reduce")
         dev = self.device
@@ -1036,26 +1039,58 @@ class Learner:
                 self.optimizer.step()
                 return torch.stack([v.detach().reshape(()), r.detach().reshape(()), p.detach().reshape(()), loss.detach()]), per.detach()
 
+            snapshot = self._snapshot_training_state()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):                         # allocations, solver choices, momentum buffers
                     body()
-                    self.scheduler.step()
-                    self.training_step += 1
             torch.cuda.current_stream().wait_stream(side)
+            self._restore_training_state(snapshot)
             graph = torch.cuda.CUDAGraph()
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
                 outs = body()
-            st = self._graph_state = {"key": key, "graph": graph, "static": static, "outs": outs, "warmup_updates": 3}
+            st = self._graph_state = {"key": key, "graph": graph, "static": static, "outs": outs}
             return self._graph_replay(st, ins)             # (the recording itself executed nothing)
         return self._graph_replay(st, ins)
+
+    def _snapshot_training_state(self):
+        """Copies of everything an update changes: parameters and buffers, momentum."""
+        net = {k: v.detach().clone() for k, v in self.network.state_dict().items()}
+        momentum = {}
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                buf = self.optimizer.state.get(p, {}).get("momentum_buffer")
+                momentum[p] = None if buf is None else buf.detach().clone()
+        return net, momentum
+
+    def _restore_training_state(self, snapshot) -> None:
+        """Write a snapshot back IN PLACE (the tensors keep their addresses: a graph recorded afterwards, and the
+        optimizer, go on using them).  A momentum buffer that did not exist at the snapshot becomes zero, from
+        which the next step leaves it equal to the gradient - what SGD's first step does."""
+        net, momentum = snapshot
+        with torch.no_grad():
+            for k, v in self.network.state_dict().items():       # detached aliases of the live tensors
+                v.copy_(net[k])
+            for p, buf in momentum.items():
+                cur = self.optimizer.state.get(p, {}).get("momentum_buffer")
+                if cur is not None:
+                    if buf is None:
+                        cur.zero_()
+                    else:
+                        cur.copy_(buf)
 
     def _graph_replay(self, st, ins):
         for dst, src in zip(st["static"], ins):
             dst.copy_(src, non_blocking=True)
         st["graph"].replay()
+        # the replay stepped the weights in place without touching their version counters, and refilled the shared
+        # packed buffers from the weights as they were BEFORE its own step: forget what is packed, so that the
+        # next eager pass packs again
+        for m in getattr(self, "_native_conv_list", None) or ():
+            for t, (_, buf) in list(m._packed._slots.items()):
+                m._packed._slots[t] = (None, buf)
         self.scheduler.step()
         self.training_step += 1
         m, per = st["outs"]

@@ -158,11 +158,10 @@ def test_graphed_update_follows_the_eager_update_fp32():
     batches = _batches(4, 4)
     eager = Learner(cfg, state_dict=sd, precision="fp32")
     graphed = Learner(cfg, state_dict=sd, precision="fp32")
-    for _ in range(3):          # the recording runs three warm-up updates on its first batch: same history for both
-        eager.update_from_tensors(*batches[0])
+    # the recording's warm-up passes leave no trace (state restored): one update per call from the first call on
     m_e = [eager.update_from_tensors(*b) for b in batches]
     m_g = [graphed.update_graphed(*b) for b in batches]
-    assert graphed.training_step == eager.training_step == 7
+    assert graphed.training_step == eager.training_step == 4
     assert graphed.scheduler.last_epoch == eager.scheduler.last_epoch
     for a, b in zip(m_g, m_e):
         print("graphed / eager total loss", a["total_loss"], b["total_loss"])
@@ -185,10 +184,14 @@ def test_graphed_update_with_native_convolutions_learns_and_repacks():
     lrn = Learner(cfg, state_dict=init_state_dict(cfg, seed=0), precision="bf16")
     assert lrn.native_convs
     batch = _batches(1, 8)[0]
+    with torch.no_grad():
+        _, _, _, per0 = lrn.losses_from_tensors(*batch)
     first = lrn.update_graphed(*batch)
-    assert lrn.training_step == 4                      # three warm-up updates + the first replay
+    assert lrn.training_step == 1                      # the warm-up passes of the recording are undone
+    # ... so the first reported loss is the loss of the initial weights
+    assert abs(first["total_loss"] - float(per0.mean())) <= 2e-2 * abs(float(per0.mean()))
     losses = [first["total_loss"]]
-    for _ in range(10):
+    for _ in range(13):
         losses.append(lrn.update_graphed(*batch)["total_loss"])
     assert lrn.training_step == 14 and lrn.scheduler.last_epoch == 14
     assert losses[-1] < 0.9 * losses[0], losses
@@ -198,6 +201,42 @@ def test_graphed_update_with_native_convolutions_learns_and_repacks():
     # undo that forward's BatchNorm statistics update? not needed: the reported loss does not depend on them
     got = lrn.update_graphed(*batch)["total_loss"]
     assert abs(got - expect) <= 1e-2 * abs(expect), (got, expect)
+
+
+def test_eager_passes_between_graph_replays_see_the_current_weights():
+    """eager loss, replays, eager loss, replays, eager loss: a replay changes the weights in place without
+    bumping their version counters and rewrites the packed copies from the weights before its own step, so an
+    eager pass after it must pack again - otherwise the native 12x12 layers would run one update behind every
+    other layer.  Reference for each eager loss: the same weights in a learner on torch's convolutions."""
+    from muzero_amd.learner import Learner
+    from muzero_amd.network import init_state_dict
+    cfg = _train_cfg(8)
+    cfg.lr_init = 0.02
+    sd = init_state_dict(cfg, seed=0)
+    lrn = Learner(cfg, state_dict=sd, precision="bf16")
+    plain = Learner(cfg, state_dict=sd, precision="bf16", native_convs=False)
+    assert lrn.native_convs and not plain.native_convs
+    batch = _batches(1, 8)[0]
+
+    def eager_pair():
+        state = {k: v.clone() for k, v in lrn.network.state_dict().items()}
+        plain.network.load_state_dict(state)
+        fresh = Learner(cfg, state_dict=state, precision="bf16")     # same kernels, nothing packed yet
+        with torch.no_grad():
+            a = float(lrn.losses_from_tensors(*batch)[3].mean())
+            b = float(plain.losses_from_tensors(*batch)[3].mean())
+            c = float(fresh.losses_from_tensors(*batch)[3].mean())
+        return a, b, c
+
+    seen = []
+    for round_ in range(3):
+        a, b, c = eager_pair()
+        seen.append(a)
+        assert abs(a - c) <= 1e-5 * abs(c), (round_, a, c)     # the same computation on the same weights
+        assert abs(a - b) <= 2e-2 * abs(b), (round_, a, b)     # two bf16 computations of the same loss
+        for _ in range(4):
+            lrn.update_graphed(*batch)
+    assert seen[2] < seen[1] < seen[0], seen                   # and the loss moves between the eager passes
 
 
 @pytest.mark.parametrize("with_residual", [False, True])
