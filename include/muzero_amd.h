@@ -492,7 +492,11 @@ int mz_replay_sample(const double* prio, int64_t n, const double* u, int32_t bat
  * carry a workspace around - code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  n must not exceed mz_replay_static_max_positions() (16 Mi positions; MZ_E_ARG otherwise).  All
  * calls on one GPU share the array: the results of a call are complete once its stream work has finished, but
- * two calls running at the same time on different streams of one GPU race on it. */
+ * two calls running at the same time on different streams of one GPU race on it.
+ * The array's device address is looked up once per GPU (hipGetSymbolAddress, a runtime query that does not belong
+ * inside a stream capture): mz_replay_static_max_positions() does it for the current device, so call that once
+ * per GPU at set-up; without it the first mz_replay_sample_static on a GPU does it, and that first call must
+ * then be made outside capture. */
 int64_t mz_replay_static_max_positions(void);
 int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int32_t batch, double beta,
                             const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game,
@@ -501,7 +505,8 @@ int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int3
 /* ReplayBuffer.update_priorities (model.py:612-614): prio[flat[i]] = (values[i] + 1e-6) ** alpha for i in list
  * order (of several entries naming one slot the last wins).  flat holds FLAT position indices as
  * mz_replay_sample returns them (the reference passes in-game offsets here, model.py:595 / :607, and so writes
- * other slots than it sampled; that is not reproduced).  Entries outside [0, n) are ignored. */
+ * other slots than it sampled; that is not reproduced).  Entries outside [0, n) are ignored.  Linear in m:
+ * the entries bid for their slot with their list index (an integer atomic on the slot), the highest writes. */
 int mz_replay_update(double* prio, int64_t n, const int32_t* flat, const double* values, int32_t m, double alpha,
                      mz_stream_t stream);
 

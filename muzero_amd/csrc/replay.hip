@@ -12,6 +12,8 @@
 // HBM-bound: one pass over the n priorities (8 B each) for the chunk sums plus 16 KB per draw.
 #pragma clang fp contract(off)
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -125,35 +127,55 @@ __global__ __launch_bounds__(256) void draw_kernel(const double* __restrict__ pr
     const double excl = incl - s;
     const unsigned long long above = __ballot((start + incl) / total > x);
     const long last_valid = (n - base < kChunk ? n - base : kChunk) - 1;
-    int src_lane;
+    // A draw must never land on a position of priority zero: its importance weight would be 1 / 0.  The running
+    // sum below restarts from start + (incl - s), which can come out an ulp away from the neighbouring lane's
+    // inclusive sum, so "the first k whose cumulative sum exceeds the draw" is taken among the lane's POSITIVE
+    // entries, and every fallback (rounding left no crossing in the lane, or none in the chunk) takes the last
+    // positive entry at or before where the crossing should have been.
+    int last_pos = -1;  // this lane's last positive entry
+#pragma unroll
+    for (int k = 0; k < kPerLane; ++k)
+      if (v[k] > 0.0) last_pos = k;
+    const unsigned long long has_pos = __ballot(last_pos >= 0);
+    int src_lane = -1;
     int k_hit = -1;
     if (above) {
       src_lane = __builtin_ctzll(above);
+      // the lane of the crossing holds a positive entry unless rounding put the crossing one lane late: then
+      // the nearest lane below it that has one
+      if (!((has_pos >> src_lane) & 1ull)) {
+        const unsigned long long below = has_pos & ((1ull << src_lane) - 1ull);
+        src_lane = below ? 63 - __builtin_clzll(below) : (has_pos ? __builtin_ctzll(has_pos) : -1);
+      }
       if (lane == src_lane) {
         double r = start + excl;
-        k_hit = kPerLane - 1;
+        k_hit = last_pos;
         bool found = false;
 #pragma unroll
         for (int k = 0; k < kPerLane; ++k) {
           r += v[k];
-          if (!found && r / total > x) { k_hit = k; found = true; }
+          if (!found && v[k] > 0.0 && r / total > x) { k_hit = k; found = true; }
         }
       }
-    } else {
-      src_lane = (int)(last_valid / kPerLane);
-      if (lane == src_lane) k_hit = (int)(last_valid % kPerLane);
+    } else if (has_pos) {
+      src_lane = 63 - __builtin_clzll(has_pos);
+      if (lane == src_lane) k_hit = last_pos;
     }
-    k_hit = __shfl(k_hit, src_lane);
-    long in_chunk = (long)src_lane * kPerLane + k_hit;
-    if (in_chunk > last_valid) in_chunk = last_valid;
-    idx = base + in_chunk;
+    if (src_lane >= 0) {
+      k_hit = __shfl(k_hit, src_lane);
+      idx = base + (long)src_lane * kPerLane + k_hit;
+    } else {
+      idx = base + last_valid;  // a chunk without any positive entry: only a draw outside [0, 1) gets here
+    }
     p_idx = prio[idx];
   }
   if (lane == 0) {
     flat[d] = (int)idx;
     const double prob = total > 0.0 ? p_idx / total : 1.0 / (double)n;
     const double t = (double)n * prob;
-    weights[d] = beta == 1.0 ? 1.0 / t : pow(t, -beta);  // normalised by the batch maximum afterwards
+    // normalised by the batch maximum afterwards; a position of priority zero while others are positive can
+    // only come from a draw outside [0, 1): weight zero (the sample is ignored) instead of infinity
+    weights[d] = t > 0.0 ? (beta == 1.0 ? 1.0 / t : pow(t, -beta)) : 0.0;
     if (game_start) {
       int a = 0, b = n_games - 1;  // last game whose first position is <= idx
       while (a < b) {
@@ -179,19 +201,31 @@ __global__ __launch_bounds__(1024) void normalise_kernel(double* __restrict__ we
     __syncthreads();
   }
   m = red[0];
+  if (!(m > 0.0)) return;
   for (int i = tid; i < batch; i += 1024) weights[i] = weights[i] / m;
 }
 
 // prio[flat[i]] = (values[i] + 1e-6) ** alpha in list order: of several entries naming one slot the
-// last one wins, as in the reference's loop (model.py:612-614)
-__global__ void update_kernel(double* __restrict__ prio, long n, const int* __restrict__ flat,
-                              const double* __restrict__ values, int m, double alpha) {
+// last one wins, as in the reference's loop (model.py:612-614).  Two passes, O(m): first every entry bids
+// for its slot with the NEGATIVE number -(i + 1) by an integer minimum on the slot's bit pattern (priorities
+// are non-negative doubles, whose patterns are non-negative integers, so any bid beats the old priority and
+// the highest list index beats every other bid); then the entry that finds its own bid in the slot writes
+// its value there.
+__global__ void update_bid_kernel(double* __restrict__ prio, long n, const int* __restrict__ flat, int m) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const int slot = flat[i];
   if (slot < 0 || slot >= n) return;
-  for (int j = i + 1; j < m; ++j)
-    if (flat[j] == slot) return;
+  atomicMin(reinterpret_cast<long long*>(prio) + slot, -(long long)(i + 1));
+}
+
+__global__ void update_write_kernel(double* __restrict__ prio, long n, const int* __restrict__ flat,
+                                    const double* __restrict__ values, int m, double alpha) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int slot = flat[i];
+  if (slot < 0 || slot >= n) return;
+  if (reinterpret_cast<const long long*>(prio)[slot] != -(long long)(i + 1)) return;
   const double v = values[i] + 1e-6;
   prio[slot] = alpha == 1.0 ? v : pow(v, alpha);
 }
@@ -224,19 +258,20 @@ constexpr long kStaticDoubles = 1 + (kStaticMaxPositions / kChunk + 1) + kStatic
 static __device__ __align__(256) double scratch[kStaticDoubles];
 
 double* static_scratch_ptr(int* rc) {
-  static double* ptr[mz::kMaxDevices] = {nullptr};
+  static std::atomic<double*> ptr[mz::kMaxDevices];
   const int dev = mz::current_device();
   *rc = MZ_OK;
-  if (!ptr[dev]) {  // once per device, with that device current: each GPU has its own copy of the array
-    double* p = nullptr;
+  double* p = ptr[dev].load(std::memory_order_acquire);
+  if (!p) {  // once per device, with that device current: each GPU has its own copy of the array.  Two threads
+             // racing here both ask the runtime and store the same address.
     const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
     if (e != hipSuccess || !p) {
       *rc = mz::fail(MZ_E_LAUNCH, "mz_replay_sample_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
       return nullptr;
     }
-    ptr[dev] = p;
+    ptr[dev].store(p, std::memory_order_release);
   }
-  return ptr[dev];
+  return p;
 }
 
 }  // namespace
@@ -257,7 +292,13 @@ int mz_replay_sample(const double* prio, int64_t n, const double* u, int32_t bat
                      weights, static_cast<double*>(workspace), mz::as_stream(stream));
 }
 
-int64_t mz_replay_static_max_positions(void) { return kStaticMaxPositions; }
+int64_t mz_replay_static_max_positions(void) {
+  // doubles as the set-up call: looks up the scratch array's address on the current device now, so that the
+  // first mz_replay_sample_static there - possibly under stream capture - makes no runtime query
+  int rc = MZ_OK;
+  static_scratch_ptr(&rc);
+  return kStaticMaxPositions;
+}
 
 int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int32_t batch, double beta,
                             const int64_t* game_start, int32_t n_games, int32_t* flat, int32_t* game,
@@ -276,8 +317,10 @@ int mz_replay_sample_static(const double* prio, int64_t n, const double* u, int3
 int mz_replay_update(double* prio, int64_t n, const int32_t* flat, const double* values, int32_t m, double alpha,
                      mz_stream_t stream) {
   MZ_REQUIRE(prio && flat && values && n >= 1 && m >= 1, "mz_replay_update: bad arguments");
-  hipLaunchKernelGGL(update_kernel, dim3((m + 255) / 256), dim3(256), 0, mz::as_stream(stream), prio, (long)n, flat,
-                     values, m, alpha);
+  hipLaunchKernelGGL(update_bid_kernel, dim3((m + 255) / 256), dim3(256), 0, mz::as_stream(stream), prio, (long)n,
+                     flat, m);
+  hipLaunchKernelGGL(update_write_kernel, dim3((m + 255) / 256), dim3(256), 0, mz::as_stream(stream), prio, (long)n,
+                     flat, values, m, alpha);
   return mz::check_launch("mz_replay_update");
 }
 

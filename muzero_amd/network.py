@@ -208,9 +208,14 @@ class MuZeroNetwork:
         allocated by the first call and REFILLED IN PLACE by later calls with the same shapes, so
         their addresses - in a recorded HIP graph of the search, say - stay valid; ``generation``
         counts the (re)allocations."""
-        dsd = {k: (v.detach().to(self.device, torch.float32).contiguous() if v.is_floating_point() else v)
-               for k, v in sd.items()}
-        structure = tuple((k, tuple(v.shape)) for k, v in sd.items())
+        def own(v):
+            # a float32 device tensor would come through .to() unchanged, i.e. as an alias of the caller's
+            # (possibly live, still training) parameter: keep a copy, so that state_dict() goes on returning
+            # what was loaded - the weights the search is using
+            t = v.detach().to(self.device, torch.float32).contiguous()
+            return t.clone() if t.data_ptr() == v.data_ptr() else t
+        dsd = {k: (own(v) if v.is_floating_point() else v.detach().clone()) for k, v in sd.items()}
+        structure = {k: tuple(v.shape) for k, v in sd.items()}       # compared as a mapping: key order is free
         if structure != getattr(self, "_structure", None):
             self._build(dsd)
             self._structure = structure

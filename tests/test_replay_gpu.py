@@ -94,3 +94,55 @@ def test_device_sampler_rejects_bad_arguments():
     with pytest.raises(_lib.MuZeroAmdError):
         _lib.call("mz_replay_sample", _lib.ptr(p), 8, _lib.ptr(u), 4, 1.0, None, 0, _lib.ptr(flat), None, None,
                   _lib.ptr(w), _lib.ptr(ws), 8, _lib.current_stream())
+
+
+def test_draws_on_boundaries_next_to_zero_priority_runs_never_pick_a_zero():
+    """Uniforms placed exactly on (and an ulp either side of) chunk boundaries, lane boundaries and the total,
+    with runs of zero priority on both sides of every boundary: every drawn position has a positive priority
+    (a zero would make its importance weight infinite and the normalised batch NaN), lies where the cumulative
+    distribution puts the draw to rounding, and all weights are finite."""
+    from muzero_amd.learner import DevicePriorities
+    rng = np.random.default_rng(17)
+    n = 5 * 2048 + 777
+    prio = rng.random(n) * 3
+    for b in list(range(0, n, 32)):                        # zero runs straddling every lane and chunk boundary
+        if rng.random() < 0.7:
+            prio[max(b - int(rng.integers(1, 40)), 0):b + int(rng.integers(1, 40))] = 0.0
+    prio[-300:] = 0.0                                       # the tail of the last chunk
+    prio[2048 * 3:2048 * 4] = 0.0                           # a whole chunk
+    assert (prio > 0).sum() > 1000
+    cdf = np.cumsum(prio) / prio.sum()
+    edges = cdf[np.arange(31, n, 32)]
+    edges = edges[edges < 1.0]
+    u = np.concatenate([edges, np.nextafter(edges, 0), np.nextafter(edges, 1), [0.0, np.nextafter(1.0, 0)]])
+    u = np.clip(u, 0.0, np.nextafter(1.0, 0))
+    dp = DevicePriorities(capacity=4)
+    dp.append_game(prio)
+    flat, game, pos, w = (t.cpu().numpy() for t in dp.sample(u, 1.0))
+    assert (prio[flat] > 0).all()
+    assert np.isfinite(w).all() and w.max() == 1.0 and (w > 0).all()
+    eps = 1e-11
+    lo = np.where(flat > 0, cdf[np.maximum(flat - 1, 0)], 0.0)
+    assert (lo <= u + eps).all() and (u < cdf[flat] + eps).all()
+
+
+def test_priority_update_is_linear_and_last_entry_wins_at_size():
+    """64 Ki entries with heavy duplication over 5 000 slots (the quadratic scan this replaces would take
+    4 G comparisons): the slot values equal a sequential last-entry-wins loop, untouched slots keep theirs."""
+    from muzero_amd.learner import DevicePriorities
+    rng = np.random.default_rng(23)
+    n, m = 200_000, 65_536
+    prio = rng.random(n) + 0.5
+    prio[::7] = 0.0                                         # zero priorities are valid old values
+    dp = DevicePriorities(capacity=4)
+    dp.append_game(prio)
+    idx = rng.choice(rng.choice(n, 5000, replace=False), m).astype(np.int32)
+    idx[::1000] = -1
+    idx[1::1000] = n + 3
+    vals = rng.random(m)
+    dp.update(idx, vals, 1.0)
+    want = prio.copy()
+    for i, v in zip(idx, vals):
+        if 0 <= i < n:
+            want[i] = v + 1e-6
+    assert np.array_equal(dp.values.cpu().numpy(), want)

@@ -155,3 +155,27 @@ def test_pack_many_equals_single_packs():
     with pytest.raises(_lib.MuZeroAmdError, match="null"):
         bad = (C.c_void_p * n)(*([w.data_ptr() for w in ws[:-1]] + [None]))
         _lib.call("mz_weights_pack_many", bad, op, tr, n, 256, 256, 256, _lib.current_stream())
+
+
+def test_loaded_parameters_are_a_snapshot_and_key_order_is_free():
+    """load_state_dict on float32 DEVICE tensors (a learner's live parameters) keeps its own copy: training on
+    after the hand-over does not change what state_dict() returns; and the same parameters in another key order
+    refill the existing buffers (no new generation, a captured search stays valid)."""
+    from collections import OrderedDict
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    cfg = MuZeroConfig()
+    cfg.action_space_size = 6
+    live = OrderedDict((k, v.cuda()) for k, v in init_state_dict(cfg, seed=4, randomize_bn=True).items())
+    net = MuZeroNetwork(cfg, precision="bf16", state_dict=live)
+    gen = net.generation
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    for v in live.values():
+        if v.is_floating_point():
+            v.add_(1.0)                                   # the learner moves on
+    after = net.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    shuffled = OrderedDict((k, before[k]) for k in reversed(list(before)))
+    net.load_state_dict(shuffled)
+    assert net.generation == gen
+    assert all(torch.equal(before[k], net.state_dict()[k]) for k in before)

@@ -36,6 +36,7 @@ def _both(prio, u, starts, beta):
 def test_static_scratch_variant_equals_workspace_variant():
     from muzero_amd import _lib
     rng = np.random.default_rng(5)
+    assert _lib.lib().mz_replay_static_max_positions() == 16 << 20     # also looks up the scratch address
     for n, batch in ((300_001, 1024), (4_099, 96)):          # the second call is smaller than the first
         prio = torch.from_numpy(rng.random(n) ** 2).cuda()
         u = torch.from_numpy(rng.random(batch)).cuda()
@@ -53,3 +54,45 @@ def test_static_scratch_variant_equals_workspace_variant():
     with pytest.raises(_lib.MuZeroAmdError, match="at most"):
         _lib.call("mz_replay_sample_static", _lib.ptr(one), cap + 1, _lib.ptr(one), 1, 1.0, None, 0, _lib.ptr(i32),
                   None, None, _lib.ptr(one), _lib.current_stream())
+
+
+def test_static_variant_allocates_nothing_and_replays_from_a_graph():
+    """Free device memory is the same before and after calls of the static entry point (the driver's view,
+    not torch's allocator: outputs are allocated beforehand), and - its scratch address looked up at set-up - the
+    entry point can be recorded into a HIP graph and replayed on new priorities and draws."""
+    from muzero_amd import _lib
+    assert _lib.lib().mz_replay_static_max_positions() == 16 << 20     # set-up: outside capture
+    rng = np.random.default_rng(6)
+    n, batch = 70_001, 256
+    prio = torch.from_numpy(rng.random(n) ** 2).cuda()
+    u = torch.from_numpy(rng.random(batch)).cuda()
+    flat = torch.empty(batch, dtype=torch.int32, device="cuda")
+    w = torch.empty(batch, dtype=torch.float64, device="cuda")
+
+    def call():
+        _lib.call("mz_replay_sample_static", _lib.ptr(prio), n, _lib.ptr(u), batch, 1.0, None, 0, _lib.ptr(flat),
+                  None, None, _lib.ptr(w), _lib.current_stream())
+    call()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call()
+    for seed in (1, 2):
+        r = np.random.default_rng(seed)
+        prio.copy_(torch.from_numpy(r.random(n) ** 2))
+        u.copy_(torch.from_numpy(r.random(batch)))
+        graph.replay()
+        torch.cuda.synchronize()
+        got_f, got_w = flat.cpu().numpy().copy(), w.cpu().numpy().copy()
+        need = _lib.lib().mz_replay_workspace_bytes(n)
+        ws = torch.empty(need // 8, dtype=torch.float64, device="cuda")
+        _lib.call("mz_replay_sample", _lib.ptr(prio), n, _lib.ptr(u), batch, 1.0, None, 0, _lib.ptr(flat), None, None,
+                  _lib.ptr(w), _lib.ptr(ws), need, _lib.current_stream())
+        torch.cuda.synchronize()
+        assert np.array_equal(got_f, flat.cpu().numpy()) and np.array_equal(got_w, w.cpu().numpy())
