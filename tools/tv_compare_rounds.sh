@@ -1,3 +1,5 @@
+# Re-measures the bf16-vs-fp32 search agreement at an older tree and at HEAD on one box.
+# Set-up (build container): git worktree add -f _r1 3ba4d59 && make -C _r1/muzero_amd/csrc -j8   (then run this on the GPU box)
 set -e
 for A in 18 6; do
  (cd _r1 && timeout -k 10 200 python tools/bf16_vs_fp32_search.py 128 $A 50) >> gpurun_out/r3_tv_r1.log 2>&1
