@@ -290,8 +290,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
 #ifdef MZ_CHAIN_STAMPS
 __device__ long long g_stamps[8192];
 #define MZ_STAMP(i) if (stamp) g_stamps[sidx + (i)] = clock64()
+// one record per launch of the two-image kernel (workgroup 0): layers, shader-clock cycles and constant-rate
+// (100 MHz) ticks from its first instruction to its last - their ratio is the clock the launch ran at
+__device__ long long g_launches[3 * 4096];
+__device__ unsigned g_launch_count;
+// per workgroup of the most recent 5-layer and 18-layer launch: first and last instruction in 100 MHz ticks
+__device__ long long g_wg_span[2][512][2];
+#define MZ_LAUNCH_BEGIN() const long long lc0 = clock64(), lw0 = wall_clock64()
+#define MZ_LAUNCH_END(layers)                                                     \
+  if (threadIdx.x == 0 && blockIdx.x < 512 && ((layers) == 5 || (layers) == 18)) {  \
+    g_wg_span[(layers) == 18][blockIdx.x][0] = lw0;                                 \
+    g_wg_span[(layers) == 18][blockIdx.x][1] = wall_clock64();                      \
+  }                                                                                \
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                                       \
+    const unsigned slot = atomicAdd(&g_launch_count, 1u) % 4096u;                   \
+    g_launches[3 * slot] = (layers);                                                \
+    g_launches[3 * slot + 1] = clock64() - lc0;                                     \
+    g_launches[3 * slot + 2] = wall_clock64() - lw0;                                \
+  }
 #else
 #define MZ_STAMP(i)
+#define MZ_LAUNCH_BEGIN()
+#define MZ_LAUNCH_END(layers)
 #endif
 
 struct ChainArgs {
@@ -599,6 +619,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 template <int PF>
 __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  MZ_LAUNCH_BEGIN();
   constexpr int NW = 8, WN = 2;
   constexpr int WSTEP = 16 * 1024;       // bytes of weight fragments per k-step
   constexpr int PSTRIDE = 2 * kPlaneB;   // LDS bytes between consecutive planes of one image
@@ -877,6 +898,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
     }
     __syncthreads();  // the next images overwrite these
   }
+  MZ_LAUNCH_END(a.n_layers);
 }
 
 template <int NW, int PF, int SPLIT>
@@ -893,6 +915,16 @@ int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
 #ifdef MZ_CHAIN_STAMPS
 extern "C" int mz_debug_read_stamps(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n);
+}
+extern "C" int mz_debug_read_wg_spans(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_span), sizeof(long long) * 2 * 512 * 2);
+}
+// the last up to 4096 launch records {layers, shader cycles, 100 MHz ticks}; returns the launch count so far
+extern "C" int mz_debug_read_launches(long long* host, int n) {
+  unsigned count = 0;
+  if (hipMemcpyFromSymbol(&count, HIP_SYMBOL(g_launch_count), sizeof(count)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_launches), sizeof(long long) * 3 * n) != hipSuccess) return -1;
+  return (int)count;
 }
 #endif
 
