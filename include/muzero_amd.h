@@ -221,6 +221,30 @@ int mz_conv_chain_mid_bf16(const void* in, const mz_chain_layer* layers, int32_t
                            mz_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * The same kernels with operands in IEEE half ("f16": 11 significant bits against bf16's 8, the same
+ * v_mfma_f32_16x16x32 rate).  Same contracts as the bf16 entry points they are named after
+ * (representation / dynamics / prediction forward, model.py:195-204, :228-245, :273-281), with half where
+ * those take bf16: activations (in, residual, out), packed weights (mz_weights_fold_pack mode 3, the same
+ * fragment order), the rotating observation (mz_obs_slot_write format 3).  float32 accumulation, bias and
+ * spatial mean as before.  Results that exceed the largest finite half (65 504) are stored as that value
+ * instead of infinity; BatchNorm-folded weights and post-ReLU activations of the reference architecture are
+ * orders of magnitude below it.
+ * ------------------------------------------------------------------ */
+int mz_conv3x3_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk,
+                   const float* bias, const void* residual, void* out, const float* action_vec,
+                   const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                   int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream);
+int mz_conv3x3_f16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,
+                       int32_t relu, mz_stream_t stream);
+int mz_conv3x3_f16_rot_sel(const void* obs_rot, const void* wpk_all, int64_t copy_elems, const int32_t* newest,
+                           const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream);
+int mz_conv_chain_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                      int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                      float* mean_out, int32_t B, mz_stream_t stream);
+int mz_conv_chain_mid_f16(const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out, int32_t B,
+                          mz_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * float32-accurate networks on the bf16 matrix cores ("bf16x3"): a float32 tensor travels as
  * bf16 pairs hi = bf16(x), lo = bf16(x - hi), laid out [image][2 = hi, lo][pixels][channels], and
  * every product is w_hi*x_hi + w_lo*x_hi + w_hi*x_lo accumulated in float32 (error ~2^-17
@@ -263,9 +287,10 @@ int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int3
  *                                                       rows >= O are zero)
  * with W1 [Hd][C], W2 [O][Hd] the torch Linear weights; b1 float [Hd];
  * b2 float [ceil(O/16)*16] zero padded.  With bf16 != 0 the two weight buffers
- * hold bf16 fragments for the 16x16x32 MFMA instead (throughput precision):
+ * hold 16-bit fragments for the 16x16x32 MFMA instead - bf16 (1, the throughput precision) or IEEE half (2):
  *   w1p[(t*(C/32) + ks)*64 + lane][j] = W1[t*16 + lane%16][32*ks + 8*(lane/16) + j]
- * (same for w2p with Hd); C and Hd must then be multiples of 32. */
+ * (same for w2p with Hd); C and Hd must then be multiples of 32, and the layer inputs (spatial means, hidden
+ * layer) are rounded to the same format. */
 typedef struct mz_head_weights {
   const void* w1p;
   const float* b1;
@@ -312,12 +337,13 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 
 /* Stacked, normalised observation from the ring: out[b][pixel][age*3 + rgb] =
  * frame(age)[pixel][rgb] / 255 with age 0 = oldest = slot (newest_slot+1) % D
- * (train.py:62-63 then :534-540). out is NHWC: float32 (out_is_bf16 = 0), bf16 (1), or the bf16x3 precision's
- * (hi, lo) bf16 pairs of the float32 value, [B][2][HW][3*D] (2; needs 3*D % 8 == 0 and HW % 64 == 0). */
+ * (train.py:62-63 then :534-540). out is NHWC: float32 (out_is_bf16 = 0), bf16 (1), IEEE half (3), or the bf16x3
+ * precision's (hi, lo) bf16 pairs of the float32 value, [B][2][HW][3*D] (2; needs 3*D % 8 == 0 and HW % 64 == 0). */
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 
-/* Rotating, tiled form of the stacked observation: obs (bf16 or float) [B][H][W/16][D][56] holds, for row y
+/* Rotating, tiled form of the stacked observation: obs (float: out_is_bf16 = 0, bf16: 1, IEEE half: 3)
+ * [B][H][W/16][D][56] holds, for row y
  * and 16-pixel tile of x, frame slot s as one run of 17 pixels x 3 values + 5 values of padding: the last pixel
  * of the tile to the left (zero for a row's first tile) followed by the tile's 16 pixels.  This call writes
  * frames uint8 [B][H*W][3], normalised by /255, into slot `slot` (all D slots when fill_all != 0, or for the
@@ -355,7 +381,8 @@ int mz_gather_stacked_obs(const uint8_t* frames, const int64_t* frame_off, const
  * model.py:143-175 in eval mode; fold in double as scale = gamma / sqrt(var + eps)):
  *   mode 0: bf16 fragments in mz_conv3x3_bf16's packing, followed by its two k-steps of zeros;
  *   mode 1: the same for the residue w - bf16(w) (the lo part of the bf16x3 precision);
- *   mode 2: float32 [tap][Cin][Cout] (mz_conv3x3_f32).
+ *   mode 2: float32 [tap][Cin][Cout] (mz_conv3x3_f32);
+ *   mode 3: IEEE-half fragments in mode 0's order (mz_conv3x3_f16 and the other f16 entry points).
  * transpose != 0 packs W'[o][i][tap] = w[i][o][8 - tap], the weights with which a convolution over the
  * output gradient gives the input gradient (square layers, no BatchNorm).  rot_depth = D > 0 writes D copies
  * mz_packed_conv_elems(...) elements apart, copy r with input channel j taken from channel
@@ -375,8 +402,8 @@ int mz_weights_fold_pack(const float* w, const float* conv_bias, const float* bn
 int mz_weights_pack_many(const float* const* w, void* const* out, const int32_t* transpose, int32_t n, int32_t Cout,
                          int32_t Cin, int32_t cin_chunk, mz_stream_t stream);
 
-/* A torch Linear layer (weight [O][K], bias [O]) in the fragment order of mz_head_weights (float32, or bf16 when
- * bf16 != 0) with the bias zero-padded to a multiple of 16. */
+/* A torch Linear layer (weight [O][K], bias [O]) in the fragment order of mz_head_weights (bf16 = 0: float32,
+ * 1: bf16, 2: IEEE half) with the bias zero-padded to a multiple of 16. */
 int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int32_t bf16, void* w_packed,
                    float* bias_padded, mz_stream_t stream);
 

@@ -51,6 +51,11 @@ _SIGNATURES = {
     "mz_conv3x3_bf16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_conv_chain_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "mz_conv_chain_mid_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
+    "mz_conv3x3_f16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
+    "mz_conv_chain_f16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "mz_conv_chain_mid_f16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
+    "mz_conv3x3_f16_rot": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "mz_conv3x3_f16_rot_sel": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mz_split_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "mz_join_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "mz_conv3x3_bf16x3": (C.c_int, [_P] * 6 + [C.c_int32] * 7 + [_P]),

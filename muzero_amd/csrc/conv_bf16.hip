@@ -26,18 +26,25 @@ int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
 int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
                     int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
                     int32_t B, hipStream_t stream);
+int conv_trunk_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                   const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                   float* mean_out, int32_t B, int32_t relu, hipStream_t stream);
+int conv_chain_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                   int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                   int32_t B, hipStream_t stream);
 }
 
 namespace {
 
+template <typename T>
 struct ConvArgs {
-  const __bf16* in;
+  const T* in;
   const int* in_slot;
   int slot_stride;
-  const __bf16* wpk;
+  const T* wpk;
   const float* bias;
-  const __bf16* residual;
-  __bf16* out;
+  const T* residual;
+  T* out;
   const float* avec;
   const int* actions;
   float* mean_out;
@@ -50,9 +57,10 @@ struct ConvArgs {
 // loads sit in straight-line code: a load inside a branch (`if (inside) v = load`) makes the compiler wait for
 // ALL outstanding loads where the branch rejoins, one full round trip per unrolled round.  So pixels outside
 // the image load a clamped address and are zeroed afterwards, and the action-vector variant is chosen once.
-template <class C, bool AV>
-__device__ __forceinline__ void stage_input_impl(char* lds, const __bf16* src, const float* av, int cc, int iy0,
+template <typename T, class C, bool AV>
+__device__ __forceinline__ void stage_input_impl(char* lds, const T* src, const float* av, int cc, int iy0,
                                                  int ix0, int tid) {
+  typedef vec8<T> bf16x8;   // eight operands of format T (the name predates the second format)
   constexpr int UPP = C::CINC / 8;  // 16-byte units per pixel
   constexpr int UNITS = C::IH * C::IW * UPP;
   constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
@@ -79,22 +87,22 @@ __device__ __forceinline__ void stage_input_impl(char* lds, const __bf16* src, c
       if constexpr (AV) {
         const float4 a0 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8);
         const float4 a1 = *reinterpret_cast<const float4*>(av + cc * C::CINC + cu * 8 + 4);
-        w[0] = (__bf16)((float)w[0] + a0.x); w[1] = (__bf16)((float)w[1] + a0.y);
-        w[2] = (__bf16)((float)w[2] + a0.z); w[3] = (__bf16)((float)w[3] + a0.w);
-        w[4] = (__bf16)((float)w[4] + a1.x); w[5] = (__bf16)((float)w[5] + a1.y);
-        w[6] = (__bf16)((float)w[6] + a1.z); w[7] = (__bf16)((float)w[7] + a1.w);
+        w[0] = to_op<T>((float)w[0] + a0.x); w[1] = to_op<T>((float)w[1] + a0.y);
+        w[2] = to_op<T>((float)w[2] + a0.z); w[3] = to_op<T>((float)w[3] + a0.w);
+        w[4] = to_op<T>((float)w[4] + a1.x); w[5] = to_op<T>((float)w[5] + a1.y);
+        w[6] = to_op<T>((float)w[6] + a1.z); w[7] = to_op<T>((float)w[7] + a1.w);
       }
-      if (!(iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN)) w = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (!(iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN)) w = zero8<T>();
       *reinterpret_cast<bf16x8*>(lds + py * C::ROWP + px * C::ROWB + cu * 16) = w;
     }
   }
 }
 
-template <class C>
-__device__ __forceinline__ void stage_input(char* lds, const __bf16* src, const float* av, int cc, int iy0, int ix0,
+template <typename T, class C>
+__device__ __forceinline__ void stage_input(char* lds, const T* src, const float* av, int cc, int iy0, int ix0,
                                             int tid) {
-  if (av) stage_input_impl<C, true>(lds, src, av, cc, iy0, ix0, tid);
-  else stage_input_impl<C, false>(lds, src, av, cc, iy0, ix0, tid);
+  if (av) stage_input_impl<T, C, true>(lds, src, av, cc, iy0, ix0, tid);
+  else stage_input_impl<T, C, false>(lds, src, av, cc, iy0, ix0, tid);
 }
 
 // The same window from the rotating, tiled observation [H][W/16][D][56] (prep.hip): the patch's 17 input
@@ -113,8 +121,9 @@ __device__ __forceinline__ unsigned quad_xor2(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
 }
 
-template <class C>
-__device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, int iy0, int ix0, int tid) {
+// (the staging moves 16-bit values without looking inside them: the same code serves both operand formats)
+template <typename T, class C>
+__device__ __forceinline__ void stage_input_rot(char* lds, const T* src, int iy0, int ix0, int tid) {
   static_assert(C::IW == 17 && C::IH == 17 && C::CIN == 96 && C::CINC == C::CIN && C::WIN % 16 == 0 &&
                 C::THREADS == 512 && C::ROWB % 8 == 0, "one 16-pixel tile, 32 slots, eight wavefronts");
   constexpr int D = C::CIN / 3, TPR = C::WIN / 16;  // slots, tiles per image row
@@ -230,8 +239,10 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const __bf16* src, in
   }
 }
 
-template <class C, bool ROT = false>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvArgs a) {
+template <typename T, class C, bool ROT = false>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvArgs<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
   // elements per image: NHWC, or the rotating layout's runs of 56 values per (row, 16-pixel tile, slot)
   constexpr long kImage = ROT ? (long)C::HIN * (C::WIN / 16) * (C::CIN / 3) * 56 : (long)C::HIN * C::WIN * C::CIN;
-  const __bf16* src = a.in + img * kImage;
+  const T* src = a.in + img * kImage;
   const float* av = a.avec ? a.avec + (long)a.actions[b] * C::CIN : nullptr;
   const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;
   const int r16 = lane & 15, kq = lane >> 4;
@@ -256,9 +267,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   // come by buffer loads: base in a scalar descriptor, k-step offset in a scalar register, the
   // lane's own offset fixed - no vector address arithmetic (reads past the array return zero)
   constexpr int WSTEP = C::NTILES * 1024;  // bytes per k-step
-  const __bf16* wbase = a.wsel ? a.wpk + (long)__builtin_amdgcn_readfirstlane(*a.wsel) * a.wsel_stride : a.wpk;
+  const T* wbase = a.wsel ? a.wpk + (long)__builtin_amdgcn_readfirstlane(*a.wsel) * a.wsel_stride : a.wpk;
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<__bf16*>(wbase), 0, (C::KSTEPS + 2) * WSTEP, 0x00020000);
+      const_cast<T*>(wbase), 0, (C::KSTEPS + 2) * WSTEP, 0x00020000);
   const int wlane = wave * (WN * 1024) + lane * 16;
   auto wfrag = [&](int step_off, int nt) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, wlane + nt * 1024, step_off, 0));
@@ -295,8 +306,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
 
   for (int cc = 0; cc < C::NCC; ++cc) {
     if (cc > 0) __syncthreads();
-    if constexpr (ROT) stage_input_rot<C>(lds, src, iy0, ix0, tid);
-    else stage_input<C>(lds, src, av, cc, iy0, ix0, tid);
+    if constexpr (ROT) stage_input_rot<T, C>(lds, src, iy0, ix0, tid);
+    else stage_input<T, C>(lds, src, av, cc, iy0, ix0, tid);
     __syncthreads();
     // software pipeline: a pixel tile's operand register is refilled with step st+1's operand
     // right after step st's MFMAs have read it
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[st % RING][nt], af[mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = mfma_16x16x32(wq[st % RING][nt], af[mt], acc[mt][nt]);
         if (st + 1 < NS) af[mt] = *(lds_frag_ptr)(abase[mt] + step_offset(st + 1));
       }
       __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
         if (a.relu) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
-        const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+        const bf16x4 ov = to_op4<T>(v0, v1, v2, v3);
         *reinterpret_cast<bf16x4*>(lds + m * OROW + cbase * 2) = ov;
       }
     }
@@ -366,10 +377,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   }
 }
 
-template <class C, bool ROT = false>
-int launch(const ConvArgs& a, int B, hipStream_t stream) {
+template <typename T, class C, bool ROT = false>
+int launch(const ConvArgs<T>& a, int B, hipStream_t stream) {
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv3x3_bf16_kernel<C, ROT>;
+  auto kern = conv3x3_bf16_kernel<T, C, ROT>;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS_BYTES, configured, "conv3x3_bf16"))
     return rc;
   hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), C::LDS_BYTES, stream, a);
@@ -379,6 +390,52 @@ int launch(const ConvArgs& a, int B, hipStream_t stream) {
 template <class C>
 bool matches(int H, int W, int Cin, int Cout, int stride) {
   return H == C::HIN && W == C::WIN && Cin == C::CIN && Cout == C::COUT && stride == C::S;
+}
+
+template <typename T>
+int conv3x3_any(const char* what, const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk,
+                const float* bias, const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu,
+                mz_stream_t stream) {
+  MZ_REQUIRE(in && wpk && bias && out && B > 0, "%s: null tensor or empty batch", what);
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "%s: action_vec and actions go together", what);
+  ConvArgs<T> a{static_cast<const T*>(in), in_slot, slot_stride, static_cast<const T*>(wpk), bias,
+                static_cast<const T*>(residual), static_cast<T*>(out), action_vec, actions, mean_out, relu};
+  hipStream_t s = mz::as_stream(stream);
+  if (H == 12 && W == 12 && Cin == 256 && Cout == 256 && stride == 1) {  // the trunk shape has its own kernel
+    if constexpr (__is_same(T, __bf16))
+      return mz::conv_trunk_bf16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B,
+                                 relu, s);
+    else
+      return mz::conv_trunk_f16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B,
+                                relu, s);
+  }
+  MZ_REQUIRE(mean_out == nullptr, "%s: the fused spatial mean needs a whole-image kernel", what);
+  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch<T, ConvStem>(a, B, s);
+  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch<T, ConvDown0>(a, B, s);
+  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch<T, ConvMid>(a, B, s);
+  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<T, ConvDown1>(a, B, s);
+  return mz::fail(MZ_E_ARG, "%s: no MFMA kernel for %dx%d, %d->%d channels, stride %d", what, H, W, Cin, Cout, stride);
+}
+
+template <typename T>
+int conv3x3_rot_any(const char* what, const void* obs_rot, const void* wpk, int64_t copy_elems, const int32_t* newest,
+                    const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(obs_rot && wpk && bias && out && B > 0, "%s: null tensor or empty batch", what);
+  MZ_REQUIRE(copy_elems % 8 == 0, "%s: weight copies must be 16-byte aligned", what);
+  ConvArgs<T> a{static_cast<const T*>(obs_rot), nullptr, 0, static_cast<const T*>(wpk), bias, nullptr,
+                static_cast<T*>(out), nullptr, nullptr, nullptr, relu, newest, (long)copy_elems};
+  return launch<T, ConvStemRot, true>(a, B, mz::as_stream(stream));
+}
+
+int check_chain_args(const char* what, const void* in, const mz_chain_layer* layers, int32_t n_layers, const void* out,
+                     const float* action_vec, const int32_t* actions, int32_t B) {
+  MZ_REQUIRE(in && layers && out && B > 0, "%s: null tensor or empty batch", what);
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= 20, "%s: n_layers must be 1..20 (got %d)", what, n_layers);
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "%s: action_vec and actions go together", what);
+  for (int l = 0; l < n_layers; ++l) MZ_REQUIRE(layers[l].wpk && layers[l].bias, "%s: layer %d is null", what, l);
+  MZ_REQUIRE(!layers[0].add_residual, "%s: the first layer has no residual source", what);
+  return MZ_OK;
 }
 
 }  // namespace
@@ -405,21 +462,16 @@ int mz_conv3x3_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
                     const float* bias, const void* residual, void* out, const float* action_vec,
                     const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
                     int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream) {
-  MZ_REQUIRE(in && wpk && bias && out && B > 0, "mz_conv3x3_bf16: null tensor or empty batch");
-  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv3x3_bf16: action_vec and actions go together");
-  ConvArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
-             static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu};
-  hipStream_t s = mz::as_stream(stream);
-  if (H == 12 && W == 12 && Cin == 256 && Cout == 256 && stride == 1)  // the trunk shape has its own kernel
-    return mz::conv_trunk_bf16(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B,
-                               relu, s);
-  MZ_REQUIRE(mean_out == nullptr, "mz_conv3x3_bf16: the fused spatial mean needs a whole-image kernel");
-  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch<ConvStem>(a, B, s);
-  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch<ConvDown0>(a, B, s);
-  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch<ConvMid>(a, B, s);
-  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch<ConvDown1>(a, B, s);
-  return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16: no MFMA kernel for %dx%d, %d->%d channels, stride %d", H, W, Cin,
-                  Cout, stride);
+  return conv3x3_any<__bf16>("mz_conv3x3_bf16", in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions,
+                             mean_out, B, H, W, Cin, Cout, stride, relu, stream);
+}
+
+int mz_conv3x3_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk,
+                   const float* bias, const void* residual, void* out, const float* action_vec,
+                   const int32_t* actions, float* mean_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                   int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream) {
+  return conv3x3_any<_Float16>("mz_conv3x3_f16", in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions,
+                               mean_out, B, H, W, Cin, Cout, stride, relu, stream);
 }
 
 int mz_conv3x3_bf16_stats(const void* in, const void* wpk, const float* bias, void* out, double* stats, int32_t B,
@@ -431,32 +483,40 @@ int mz_conv3x3_bf16_stats(const void* in, const void* wpk, const float* bias, vo
 
 int mz_conv3x3_bf16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B,
                         int32_t relu, mz_stream_t stream) {
-  MZ_REQUIRE(obs_rot && wpk && bias && out && B > 0, "mz_conv3x3_bf16_rot: null tensor or empty batch");
-  ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk), bias, nullptr,
-             static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu};
-  return launch<ConvStemRot, true>(a, B, mz::as_stream(stream));
+  return conv3x3_rot_any<__bf16>("mz_conv3x3_bf16_rot", obs_rot, wpk, 0, nullptr, bias, out, B, relu, stream);
 }
 
 int mz_conv3x3_bf16_rot_sel(const void* obs_rot, const void* wpk_all, int64_t copy_elems, const int32_t* newest,
                             const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream) {
-  MZ_REQUIRE(obs_rot && wpk_all && newest && bias && out && B > 0 && copy_elems > 0,
-             "mz_conv3x3_bf16_rot_sel: null tensor or empty batch");
-  MZ_REQUIRE(copy_elems % 8 == 0, "mz_conv3x3_bf16_rot_sel: weight copies must be 16-byte aligned");
-  ConvArgs a{static_cast<const __bf16*>(obs_rot), nullptr, 0, static_cast<const __bf16*>(wpk_all), bias, nullptr,
-             static_cast<__bf16*>(out), nullptr, nullptr, nullptr, relu, newest, (long)copy_elems};
-  return launch<ConvStemRot, true>(a, B, mz::as_stream(stream));
+  MZ_REQUIRE(newest && copy_elems > 0, "mz_conv3x3_bf16_rot_sel: null index or empty copies");
+  return conv3x3_rot_any<__bf16>("mz_conv3x3_bf16_rot_sel", obs_rot, wpk_all, copy_elems, newest, bias, out, B, relu, stream);
+}
+
+int mz_conv3x3_f16_rot(const void* obs_rot, const void* wpk, const float* bias, void* out, int32_t B, int32_t relu,
+                       mz_stream_t stream) {
+  return conv3x3_rot_any<_Float16>("mz_conv3x3_f16_rot", obs_rot, wpk, 0, nullptr, bias, out, B, relu, stream);
+}
+
+int mz_conv3x3_f16_rot_sel(const void* obs_rot, const void* wpk_all, int64_t copy_elems, const int32_t* newest,
+                           const float* bias, void* out, int32_t B, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(newest && copy_elems > 0, "mz_conv3x3_f16_rot_sel: null index or empty copies");
+  return conv3x3_rot_any<_Float16>("mz_conv3x3_f16_rot_sel", obs_rot, wpk_all, copy_elems, newest, bias, out, B, relu, stream);
 }
 
 int mz_conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
                        int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
                        float* mean_out, int32_t B, mz_stream_t stream) {
-  MZ_REQUIRE(in && layers && out && B > 0, "mz_conv_chain_bf16: null tensor or empty batch");
-  MZ_REQUIRE(n_layers >= 1 && n_layers <= 20, "mz_conv_chain_bf16: n_layers must be 1..20 (got %d)", n_layers);
-  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv_chain_bf16: action_vec and actions go together");
-  for (int l = 0; l < n_layers; ++l) MZ_REQUIRE(layers[l].wpk && layers[l].bias, "mz_conv_chain_bf16: layer %d is null", l);
-  MZ_REQUIRE(!layers[0].add_residual, "mz_conv_chain_bf16: the first layer has no residual source");
+  if (int rc = check_chain_args("mz_conv_chain_bf16", in, layers, n_layers, out, action_vec, actions, B)) return rc;
   return mz::conv_chain_bf16(in, in_slot, slot_stride, layers, n_layers, out, action_vec, actions, mean_out, B,
                              mz::as_stream(stream));
+}
+
+int mz_conv_chain_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                      int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
+                      float* mean_out, int32_t B, mz_stream_t stream) {
+  if (int rc = check_chain_args("mz_conv_chain_f16", in, layers, n_layers, out, action_vec, actions, B)) return rc;
+  return mz::conv_chain_f16(in, in_slot, slot_stride, layers, n_layers, out, action_vec, actions, mean_out, B,
+                            mz::as_stream(stream));
 }
 
 }  // extern "C"

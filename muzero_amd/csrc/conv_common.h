@@ -9,6 +9,67 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- the 16-bit operand format of a matrix-core kernel: __bf16 (8 significant bits, float32's exponent range) or
+// _Float16 (IEEE half: 11 significant bits, largest finite value 65 504).  v_mfma_f32_16x16x32 runs both at the
+// same rate; the kernels are templates over the format and differ only in the helpers below.
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_16x16x32(vec8<__bf16> a, vec8<__bf16> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(vec8<_Float16> a, vec8<_Float16> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ vec8<T> zero8() {
+  return __builtin_bit_cast(vec8<T>, u32x4_t{0u, 0u, 0u, 0u});
+}
+
+// float32 -> operand format, round to nearest even.  IEEE half saturates at its largest finite value instead of
+// overflowing to infinity (one v_med3_f32 in front of the conversion).
+template <typename T> __device__ __forceinline__ T to_op(float v);
+template <> __device__ __forceinline__ __bf16 to_op<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 to_op<_Float16>(float v) {
+  return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+}
+// max(v, floor) for an epilogue whose result is converted next: for IEEE half the saturation rides in the same
+// instruction (v_med3_f32 between the floor and the largest finite value), and to_op_unclamped follows
+template <typename T> __device__ __forceinline__ float floor_for_op(float v, float floor_v);
+template <> __device__ __forceinline__ float floor_for_op<__bf16>(float v, float floor_v) { return fmaxf(v, floor_v); }
+template <> __device__ __forceinline__ float floor_for_op<_Float16>(float v, float floor_v) {
+  return __builtin_amdgcn_fmed3f(v, floor_v, 65504.f);      // floor_v is 0 or -65504 (op_floor)
+}
+template <typename T> __device__ __forceinline__ float op_floor(bool relu);
+template <> __device__ __forceinline__ float op_floor<__bf16>(bool relu) { return relu ? 0.f : -__builtin_inff(); }
+template <> __device__ __forceinline__ float op_floor<_Float16>(bool relu) { return relu ? 0.f : -65504.f; }
+template <typename T> __device__ __forceinline__ vec4<T> to_op4_unclamped(float a, float b, float c, float d) {
+  return vec4<T>{(T)a, (T)b, (T)c, (T)d};
+}
+template <typename T> __device__ __forceinline__ vec4<T> to_op4(float a, float b, float c, float d) {
+  return vec4<T>{to_op<T>(a), to_op<T>(b), to_op<T>(c), to_op<T>(d)};
+}
+
+// The two 16-bit values of a dword as float32 - or two zeros when the kernel does not want them (a layer whose
+// successor adds no residual).  bf16: one instruction each (AND for the upper half, byte permute for the lower;
+// selector 0x0c = zero); half: an AND on the dword, then the two conversions.
+template <typename T> struct PairToFloat;
+template <> struct PairToFloat<__bf16> {
+  unsigned hi, lo;
+  __device__ __forceinline__ explicit PairToFloat(bool keep)
+      : hi(keep ? 0xffff0000u : 0u), lo(keep ? 0x01000c0cu : 0x0c0c0c0cu) {}
+  __device__ __forceinline__ float even(unsigned r) const { return __uint_as_float(__builtin_amdgcn_perm(r, r, lo)); }
+  __device__ __forceinline__ float odd(unsigned r) const { return __uint_as_float(r & hi); }
+};
+template <> struct PairToFloat<_Float16> {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  unsigned mask;
+  __device__ __forceinline__ explicit PairToFloat(bool keep) : mask(keep ? 0xffffffffu : 0u) {}
+  __device__ __forceinline__ float even(unsigned r) const { return (float)__builtin_bit_cast(h2, r & mask)[0]; }
+  __device__ __forceinline__ float odd(unsigned r) const { return (float)__builtin_bit_cast(h2, r & mask)[1]; }
+};
+
 // Sum over the 16 lanes of a row (lanes with the same lane >> 4), returned in each of them: quad permutes and row
 // mirrors pair the same groups of lanes as a butterfly of exchanges at distances 1, 2, 4, 8 would - the same tree
 // of additions, the same bits - without four trips through the LDS crossbar.

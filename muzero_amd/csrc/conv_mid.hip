@@ -33,12 +33,13 @@ constexpr int mGT = 9;                             // pixel tiles per accumulato
 constexpr int mWStep = (mCh / 16) * 1024;          // bytes of weight fragments per k-step: 8 output tiles x 1 KB
 constexpr int mMaxChain = 8;
 
+template <typename T>
 struct MidArgs {
-  const __bf16* in;
-  __bf16* out;
+  const T* in;
+  T* out;
   int B;
   int n_layers;
-  const __bf16* wpk[mMaxChain];
+  const T* wpk[mMaxChain];
   const float* bias[mMaxChain];
   unsigned relu_mask;  // bit l: ReLU after layer l
   unsigned res_mask;   // bit l: layer l adds the input of layer l - 1 before the ReLU
@@ -52,7 +53,10 @@ __host__ __device__ constexpr unsigned long long mid_edge_lanes(int mt, bool rig
   return lane < 0 ? 0ull : 0x0001000100010001ull << lane;
 }
 
-__global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NW = 8, WN = 2;
   constexpr int KOFF = mPlaneB;       // LDS bytes between consecutive 32-channel k-steps
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
   auto plane_of = [](int q) { return (q & 3) * mKC + (q >> 2); };  // channel chunk q -> plane
 
   {  // zero pixels: the 32 in front and the 32 behind every plane (never written afterwards)
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 z = zero8<T>();
     for (int s = tid; s < (mPlanes + 1) * mZero; s += NW * 64) {
       const int p = s / mZero, r = s - p * mZero;  // p == 0: the front block
       char* dst = p == 0 ? lds + r * 16 : img + (p - 1) * mPlaneB + (mPix + r) * 16;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
   };
   auto wdesc = [&](int l) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * mKC + 2) * mWStep, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.wpk[l]), 0, (9 * mKC + 2) * mWStep, 0x00020000);
   };
   const int pl = lane & 15, qq = lane >> 4;
 
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
     int plv = pl, qqv = qq;
     asm volatile("" : "+v"(plv), "+v"(qqv));
     {  // image -> LDS (planar); 144 blocks of (16 pixels x 4 channel chunks)
-      const __bf16* src = a.in + (long)b * (mPix * mCh);
+      const T* src = a.in + (long)b * (mPix * mCh);
 #pragma unroll
       for (int j = 0; j < 144 / NW; ++j) {
         const int it = wave + NW * j;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
           for (int mt = 0; mt < mGT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[nt], af[mt], acc[0][mt][nt], 0, 0, 0);
+              acc[0][mt][nt] = mfma_16x16x32(wq[nt], af[mt], acc[0][mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + goff[mt % 3] + kc * KOFF);
           }
           __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
           for (int mt = 0; mt < mGT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[nt], af[mt], acc[1][mt][nt], 0, 0, 0);
+              acc[1][mt][nt] = mfma_16x16x32(wq[nt], af[mt], acc[1][mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < mKC - 1 ? (kc + 1) * KOFF : 0));
           }
 #pragma unroll
@@ -227,10 +231,9 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
       }
       // epilogue: a lane holds channels cbase..cbase+3 (half a 16-byte chunk) of pixel (tile * 16 + r16);
       // results replace the layer's input in place
-      const float floor_v = relu ? 0.f : -__builtin_inff();
-      // bf16 pair -> two floats or two zeros, one instruction each (AND for the upper half, byte
-      // permute for the lower; selector 0x0c = zero)
-      const unsigned keep_hi = keep_input ? 0xffff0000u : 0u, keep_lo = keep_input ? 0x01000c0cu : 0x0c0c0c0cu;
+      const float floor_v = op_floor<T>(relu);
+      // the input's 16-bit pairs -> two floats, or two zeros (PairToFloat: one or two instructions per value)
+      const PairToFloat<T> kept(keep_input);
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -240,13 +243,12 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
 #pragma unroll
           for (int mt = 0; mt < mGT; ++mt) {
             char* slot = plane + mt * 256;
-            const float v0 = fmaxf(acc[g][mt][nt][0] + bv[nt].x, floor_v), v1 = fmaxf(acc[g][mt][nt][1] + bv[nt].y, floor_v);
-            const float v2 = fmaxf(acc[g][mt][nt][2] + bv[nt].z, floor_v), v3 = fmaxf(acc[g][mt][nt][3] + bv[nt].w, floor_v);
+            const float v0 = floor_for_op<T>(acc[g][mt][nt][0] + bv[nt].x, floor_v), v1 = floor_for_op<T>(acc[g][mt][nt][1] + bv[nt].y, floor_v);
+            const float v2 = floor_for_op<T>(acc[g][mt][nt][2] + bv[nt].z, floor_v), v3 = floor_for_op<T>(acc[g][mt][nt][3] + bv[nt].w, floor_v);
             // the next layer's starting value: this layer's input where the next layer adds it, else zero
             const uint2 r = *reinterpret_cast<const uint2*>(slot);
-            acc[g][mt][nt] = f32x4{__uint_as_float(__builtin_amdgcn_perm(r.x, r.x, keep_lo)), __uint_as_float(r.x & keep_hi),
-                                   __uint_as_float(__builtin_amdgcn_perm(r.y, r.y, keep_lo)), __uint_as_float(r.y & keep_hi)};
-            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            acc[g][mt][nt] = f32x4{kept.even(r.x), kept.odd(r.x), kept.even(r.y), kept.odd(r.y)};
+            const bf16x4 ov = to_op4_unclamped<T>(v0, v1, v2, v3);
             *reinterpret_cast<bf16x4*>(slot) = ov;
           }
         }
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
     plv = pl, qqv = qq;
     asm volatile("" : "+v"(plv), "+v"(qqv));
     {  // result -> global, same (16 pixels x 4 chunks) blocks as the load
-      __bf16* dst = a.out + (long)b * (mPix * mCh);
+      T* dst = a.out + (long)b * (mPix * mCh);
 #pragma unroll
       for (int j = 0; j < 144 / NW; ++j) {
         const int it = wave + NW * j;
@@ -267,34 +269,46 @@ __global__ __launch_bounds__(512, 2) void conv_mid_chain_kernel(MidArgs a) {
     }
     __syncthreads();  // the next image overwrites this one
   }
-  if (a.B < 0) a.out[tid] = (__bf16)__int_as_float(touched);  // never true: B > 0 is checked by the host
+  if (a.B < 0) a.out[tid] = (T)__int_as_float(touched);  // never true: B > 0 is checked by the host
 }
 
 }  // namespace
 
-extern "C" int mz_conv_chain_mid_bf16(const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out,
-                                      int32_t B, mz_stream_t stream) {
-  MZ_REQUIRE(in && layers && out && B > 0, "mz_conv_chain_mid_bf16: null tensor or empty batch");
-  MZ_REQUIRE(n_layers >= 1 && n_layers <= mMaxChain, "mz_conv_chain_mid_bf16: n_layers = %d outside 1..%d", n_layers,
-             mMaxChain);
-  MidArgs a{};
-  a.in = static_cast<const __bf16*>(in);
-  a.out = static_cast<__bf16*>(out);
+namespace {
+template <typename T>
+int conv_mid_chain_any(const char* what, const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out,
+                       int32_t B, mz_stream_t stream) {
+  MZ_REQUIRE(in && layers && out && B > 0, "%s: null tensor or empty batch", what);
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= mMaxChain, "%s: n_layers = %d outside 1..%d", what, n_layers, mMaxChain);
+  MidArgs<T> a{};
+  a.in = static_cast<const T*>(in);
+  a.out = static_cast<T*>(out);
   a.B = B;
   a.n_layers = n_layers;
   for (int l = 0; l < n_layers; ++l) {
-    MZ_REQUIRE(layers[l].wpk && layers[l].bias, "mz_conv_chain_mid_bf16: layer %d has a null tensor", l);
-    MZ_REQUIRE(!(layers[l].add_residual && l == 0), "mz_conv_chain_mid_bf16: the first layer has no block input to add");
-    a.wpk[l] = static_cast<const __bf16*>(layers[l].wpk);
+    MZ_REQUIRE(layers[l].wpk && layers[l].bias, "%s: layer %d has a null tensor", what, l);
+    MZ_REQUIRE(!(layers[l].add_residual && l == 0), "%s: the first layer has no block input to add", what);
+    a.wpk[l] = static_cast<const T*>(layers[l].wpk);
     a.bias[l] = layers[l].bias;
     if (layers[l].relu) a.relu_mask |= 1u << l;
     if (layers[l].add_residual) a.res_mask |= 1u << l;
   }
   static bool configured[mz::kMaxDevices] = {false};
-  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_mid_chain_kernel), mLdsBytes, configured,
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_mid_chain_kernel<T>), mLdsBytes, configured,
                                       "conv_mid_chain"))
     return rc;
   const int n_cu = mz::compute_units();
-  hipLaunchKernelGGL(conv_mid_chain_kernel, dim3(B < n_cu ? B : n_cu), dim3(512), mLdsBytes, mz::as_stream(stream), a);
-  return mz::check_launch("mz_conv_chain_mid_bf16");
+  hipLaunchKernelGGL(conv_mid_chain_kernel<T>, dim3(B < n_cu ? B : n_cu), dim3(512), mLdsBytes, mz::as_stream(stream), a);
+  return mz::check_launch(what);
+}
+}  // namespace
+
+extern "C" int mz_conv_chain_mid_bf16(const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out,
+                                      int32_t B, mz_stream_t stream) {
+  return conv_mid_chain_any<__bf16>("mz_conv_chain_mid_bf16", in, layers, n_layers, out, B, stream);
+}
+
+extern "C" int mz_conv_chain_mid_f16(const void* in, const mz_chain_layer* layers, int32_t n_layers, void* out,
+                                     int32_t B, mz_stream_t stream) {
+  return conv_mid_chain_any<_Float16>("mz_conv_chain_mid_f16", in, layers, n_layers, out, B, stream);
 }

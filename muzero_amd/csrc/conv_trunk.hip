@@ -20,14 +20,15 @@
 
 namespace {
 
+template <typename T>
 struct TrunkArgs {
-  const __bf16* in;
+  const T* in;
   const int* in_slot;
   int slot_stride;
-  const __bf16* wpk;
+  const T* wpk;
   const float* bias;
-  const __bf16* residual;
-  __bf16* out;
+  const T* residual;
+  T* out;
   const float* avec;
   const int* actions;
   float* mean_out;
@@ -35,8 +36,9 @@ struct TrunkArgs {
   double* stats;  // optional [image][2][256]: per-channel sum and sum of squares of the image's (rounded) outputs
 };
 
-template <int NW>
-__device__ __forceinline__ void stage_image(char* lds, const __bf16* src, const float* av, int wave, int lane) {
+template <typename T, int NW>
+__device__ __forceinline__ void stage_image(char* lds, const T* src, const float* av, int wave, int lane) {
+  typedef vec8<T> bf16x8;   // eight operands of format T (the name predates the second format)
   // 72 blocks of (16 pixels x 4 channel chunks); lane = chunk*16 + pixel: global reads are
   // 64-byte runs per pixel, LDS writes are 16 consecutive slots per 16 lanes
   // all loads first, in straight-line code (a load inside `if (av)` would be waited for where the branch
@@ -54,10 +56,10 @@ __device__ __forceinline__ void stage_image(char* lds, const __bf16* src, const 
       const int q = ((wave + NW * j) & 7) * 4 + qq;
       const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
       const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-      v[j][0] = (__bf16)((float)v[j][0] + a0.x); v[j][1] = (__bf16)((float)v[j][1] + a0.y);
-      v[j][2] = (__bf16)((float)v[j][2] + a0.z); v[j][3] = (__bf16)((float)v[j][3] + a0.w);
-      v[j][4] = (__bf16)((float)v[j][4] + a1.x); v[j][5] = (__bf16)((float)v[j][5] + a1.y);
-      v[j][6] = (__bf16)((float)v[j][6] + a1.z); v[j][7] = (__bf16)((float)v[j][7] + a1.w);
+      v[j][0] = to_op<T>((float)v[j][0] + a0.x); v[j][1] = to_op<T>((float)v[j][1] + a0.y);
+      v[j][2] = to_op<T>((float)v[j][2] + a0.z); v[j][3] = to_op<T>((float)v[j][3] + a0.w);
+      v[j][4] = to_op<T>((float)v[j][4] + a1.x); v[j][5] = to_op<T>((float)v[j][5] + a1.y);
+      v[j][6] = to_op<T>((float)v[j][6] + a1.z); v[j][7] = to_op<T>((float)v[j][7] + a1.w);
     }
   }
 #pragma unroll
@@ -67,7 +69,7 @@ __device__ __forceinline__ void stage_image(char* lds, const __bf16* src, const 
     *reinterpret_cast<bf16x8*>(lds + q * kPlaneB + pix * 16) = v[j];
   }
   // zero pixels 144..159 of every plane: 32 planes x 16 slots = 512 slots
-  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16x8 z = zero8<T>();
   for (int s = wave * 64 + lane; s < kPlanes * 16; s += NW * 64)
     *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
 }
@@ -81,8 +83,10 @@ constexpr int kLdsTotal = kLdsBytes + kOutBytes;  // 157 952 of the CU's 163 840
 // SPLIT workgroups share one image, each computing 256 / SPLIT of the output channels (its own staging of the
 // image, the same accumulation order per output: results do not depend on SPLIT).  SPLIT = 2 serves batches
 // of at most half as many images as there are CUs - a training batch of 128.
-template <int NW, int PF, int SPLIT = 1>
-__global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a) {
+template <typename T, int NW, int PF, int SPLIT = 1>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* ldsB = lds + kLdsBytes;
   constexpr int WN = 16 / (NW * SPLIT);  // 16-channel output tiles per wavefront
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   const int b = blockIdx.x / SPLIT;
   const int tile0 = ((blockIdx.x % SPLIT) * NW + wave) * WN;  // this wavefront's first 16-channel tile
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
-  const __bf16* src = a.in + img * (long)(kPix * kCh);
+  const T* src = a.in + img * (long)(kPix * kCh);
   const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
   const int r16 = lane & 15, kq = lane >> 4;
 
@@ -107,9 +111,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   }
   wp += PF * WSTEP;
 
-  stage_image<NW>(lds, src, av, wave, lane);
+  stage_image<T, NW>(lds, src, av, wave, lane);
   if (a.residual) {  // whole rows, 16 bytes per lane: coalesced in global memory and in LDS
-    const __bf16* rs = a.residual + (long)b * (kPix * kCh);
+    const T* rs = a.residual + (long)b * (kPix * kCh);
 #pragma unroll
     for (int j = 0; j < kPix * 32 / (64 * NW); ++j) {
       const int u = tid + 64 * NW * j, pix = u >> 5, c16 = u & 31;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
       for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[nt], cur[mt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = mfma_16x16x32(w0[nt], cur[mt], acc[mt][nt]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) {
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
         v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
       }
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-      const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+      const bf16x4 ov = to_op4<T>(v0, v1, v2, v3);
       if (a.stats) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_trunk_kernel(TrunkArgs a
   }
   __syncthreads();
   // epilogue, part 2: the finished image leaves LDS as whole 512-byte rows, 16 bytes per lane
-  __bf16* dst = a.out + (long)b * (kPix * kCh);
+  T* dst = a.out + (long)b * (kPix * kCh);
   constexpr int UPP = 32 / SPLIT;  // 16-byte units per pixel that this workgroup produced
 #pragma unroll
   for (int j = 0; j < (kPix * UPP + 64 * NW - 1) / (64 * NW); ++j) {
@@ -314,24 +318,27 @@ __device__ long long g_wg_span[2][512][2];
 #define MZ_LAUNCH_END(layers)
 #endif
 
+template <typename T>
 struct ChainArgs {
-  const __bf16* in;
+  const T* in;
   const int* in_slot;
   int slot_stride;
-  __bf16* out;
+  T* out;
   const float* avec;
   const int* actions;
   float* mean_out;
   int B;
   int n_layers;
-  const __bf16* wpk[kMaxChain];
+  const T* wpk[kMaxChain];
   const float* bias[kMaxChain];
   unsigned relu_mask;  // bit l: ReLU after layer l
   unsigned res_mask;   // bit l: add the destination buffer's content (residual) before the ReLU
 };
 
-template <int NW, int PF>
-__global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a) {
+template <typename T, int NW, int PF>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int WN = 16 / NW;
   constexpr int WSTEP = 16 * 1024;  // bytes of weight fragments per k-step (16 channel tiles x 1 KB)
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 
   // zero pixels of both buffers (never written afterwards)
   {
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 z = zero8<T>();
     for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64) {
       const int buf = s >> 9, r = s & 511;
       *reinterpret_cast<bf16x8*>(lds + buf * kLdsBytes + (r >> 4) * kPlaneB + (kPix + (r & 15)) * 16) = z;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
   int touched = 0;  // sink of the next-image prefetch loads (keeps them alive; never stored)
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
-    const __bf16* src = a.in + img * (long)(kPix * kCh);
+    const T* src = a.in + img * (long)(kPix * kCh);
     const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
     // this workgroup's next image: one 4-byte load per 128-byte line pulls all 72 KB of it towards
     // L2 while the last layer of the current image computes (every workgroup otherwise fetches its
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
       return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
     };
     auto wdesc = [&](int l) {
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t wr = wdesc(0);
     int wp = 0;
@@ -428,10 +435,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           const int q = ((wave + NW * j) & 7) * 4 + qq;
           const float4 a0 = *reinterpret_cast<const float4*>(av + q * 8);
           const float4 a1 = *reinterpret_cast<const float4*>(av + q * 8 + 4);
-          v[j][0] = (__bf16)((float)v[j][0] + a0.x); v[j][1] = (__bf16)((float)v[j][1] + a0.y);
-          v[j][2] = (__bf16)((float)v[j][2] + a0.z); v[j][3] = (__bf16)((float)v[j][3] + a0.w);
-          v[j][4] = (__bf16)((float)v[j][4] + a1.x); v[j][5] = (__bf16)((float)v[j][5] + a1.y);
-          v[j][6] = (__bf16)((float)v[j][6] + a1.z); v[j][7] = (__bf16)((float)v[j][7] + a1.w);
+          v[j][0] = to_op<T>((float)v[j][0] + a0.x); v[j][1] = to_op<T>((float)v[j][1] + a0.y);
+          v[j][2] = to_op<T>((float)v[j][2] + a0.z); v[j][3] = to_op<T>((float)v[j][3] + a0.w);
+          v[j][4] = to_op<T>((float)v[j][4] + a1.x); v[j][5] = to_op<T>((float)v[j][5] + a1.y);
+          v[j][6] = to_op<T>((float)v[j][6] + a1.z); v[j][7] = to_op<T>((float)v[j][7] + a1.w);
         }
       }
 #pragma unroll
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
           for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = mfma_16x16x32(wq[0][nt], af[mt], acc[mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
           }
           // issue order inside the step: the two weight loads, then one LDS read of the NEXT
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
               v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
             }
             if (kMean) { s0 += v0; s1 += v1; s2 += v2; s3 += v3; }
-            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            const bf16x4 ov = to_op4<T>(v0, v1, v2, v3);
             *reinterpret_cast<bf16x4*>(slot) = ov;
           }
           if (kMean) {
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 
     {  // final buffer -> global, same (16 pixels x 4 chunks) blocks as the load
       const char* fbuf = lds + (a.n_layers & 1) * kLdsBytes;
-      __bf16* dst = a.out + (long)b * (kPix * kCh);
+      T* dst = a.out + (long)b * (kPix * kCh);
       const int pl = lane & 15, qq = lane >> 4;
 #pragma unroll
       for (int j = 0; j < 72 / NW; ++j) {
@@ -616,8 +623,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_chain_kernel(ChainArgs a
 // next k-step after image 1), so 9 operand registers serve both images with the
 // same 18-MFMA lead as in the single-image loop.
 // ---------------------------------------------------------------------------
-template <int PF>
-__global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
+template <typename T, int PF>
+__global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   MZ_LAUNCH_BEGIN();
   constexpr int NW = 8, WN = 2;
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
   auto plane_of = [](int q) { return (q & 3) * 8 + (q >> 2); };  // channel chunk q -> plane of its image
 
   {  // zero pixels of all 64 planes (never written afterwards)
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 z = zero8<T>();
     for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64)
       *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
   }
@@ -658,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
   };
   auto wdesc = [&](int l) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.wpk[l]), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
   };
   // Loads in this kernel are unconditional, with a valid stand-in address where the real one does not apply: a
   // load inside a branch makes the compiler wait for every outstanding load where the branch rejoins, which
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
     for (int i = 0; i < 4; ++i) slot[i] = slot_p[a.in_slot ? bsel[i] : 0];
 #pragma unroll
     for (int i = 0; i < 2; ++i) act[i] = act_p[a.avec ? bimg[i] : 0];
-    const __bf16* isrc[4];
+    const T* isrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long img = a.in_slot ? (long)__builtin_amdgcn_readfirstlane(slot[i]) * a.slot_stride + bsel[i] : bsel[i];
@@ -727,10 +736,10 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
         for (int j = 0; j < 72 / NW; ++j) {
           bf16x8 w = v[i][j];
           if (a.avec) {
-            w[0] = (__bf16)((float)w[0] + a0[i].x); w[1] = (__bf16)((float)w[1] + a0[i].y);
-            w[2] = (__bf16)((float)w[2] + a0[i].z); w[3] = (__bf16)((float)w[3] + a0[i].w);
-            w[4] = (__bf16)((float)w[4] + a1[i].x); w[5] = (__bf16)((float)w[5] + a1[i].y);
-            w[6] = (__bf16)((float)w[6] + a1[i].z); w[7] = (__bf16)((float)w[7] + a1[i].w);
+            w[0] = to_op<T>((float)w[0] + a0[i].x); w[1] = to_op<T>((float)w[1] + a0[i].y);
+            w[2] = to_op<T>((float)w[2] + a0[i].z); w[3] = to_op<T>((float)w[3] + a0[i].w);
+            w[4] = to_op<T>((float)w[4] + a1[i].x); w[5] = to_op<T>((float)w[5] + a1[i].y);
+            w[6] = to_op<T>((float)w[6] + a1[i].z); w[7] = to_op<T>((float)w[7] + a1[i].w);
           }
           *reinterpret_cast<bf16x8*>(lds + (plane_of(q) * 2 + i) * kPlaneB + (j * 16 + plv) * 16) = w;
         }
@@ -785,7 +794,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
           for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[0][mt][nt], 0, 0, 0);
+              acc[0][mt][nt] = mfma_16x16x32(wq[0][nt], af[mt], acc[0][mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kPlaneB + kc * KOFF));
           }
           __builtin_amdgcn_sched_group_barrier(0x020, WN, 0);
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
           for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-              acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][nt], af[mt], acc[1][mt][nt], 0, 0, 0);
+              acc[1][mt][nt] = mfma_16x16x32(wq[0][nt], af[mt], acc[1][mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
           }
 #pragma unroll
@@ -843,10 +852,9 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
       }
       // epilogue: lane holds channels cbase..cbase+3 (8 bytes = half a 16-byte chunk) of pixel
       // mt*16 + r16 of both images; results replace the layer's input in place
-      const float floor_v = relu ? 0.f : -__builtin_inff();
-      // bf16 pair -> two floats or two zeros, one instruction each: the odd element is the dword's
-      // upper half (AND), the even one its lower half moved up (byte permute; selector 0x0c = zero)
-      const unsigned keep_hi = keep_input ? 0xffff0000u : 0u, keep_lo = keep_input ? 0x01000c0cu : 0x0c0c0c0cu;
+      const float floor_v = op_floor<T>(relu);
+      // the input's 16-bit pairs -> two floats, or two zeros (PairToFloat: one or two instructions per value)
+      const PairToFloat<T> kept(keep_input);
       const bool want_mean = last && a.mean_out;
       // one straight path for every layer kind (selects, not branches, around the accumulators)
 #pragma unroll
@@ -859,14 +867,13 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt) {
             char* slot = plane + (mt * 16 + r16) * 16;
-            const float v0 = fmaxf(acc[i][mt][nt][0] + bv[nt].x, floor_v), v1 = fmaxf(acc[i][mt][nt][1] + bv[nt].y, floor_v);
-            const float v2 = fmaxf(acc[i][mt][nt][2] + bv[nt].z, floor_v), v3 = fmaxf(acc[i][mt][nt][3] + bv[nt].w, floor_v);
+            const float v0 = floor_for_op<T>(acc[i][mt][nt][0] + bv[nt].x, floor_v), v1 = floor_for_op<T>(acc[i][mt][nt][1] + bv[nt].y, floor_v);
+            const float v2 = floor_for_op<T>(acc[i][mt][nt][2] + bv[nt].z, floor_v), v3 = floor_for_op<T>(acc[i][mt][nt][3] + bv[nt].w, floor_v);
             // the next layer's starting value: this layer's input where the next layer adds it, else zero
             const uint2 r = *reinterpret_cast<const uint2*>(slot);
-            acc[i][mt][nt] = f32x4{__uint_as_float(__builtin_amdgcn_perm(r.x, r.x, keep_lo)), __uint_as_float(r.x & keep_hi),
-                                   __uint_as_float(__builtin_amdgcn_perm(r.y, r.y, keep_lo)), __uint_as_float(r.y & keep_hi)};
+            acc[i][mt][nt] = f32x4{kept.even(r.x), kept.odd(r.x), kept.even(r.y), kept.odd(r.y)};
             s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-            const bf16x4 ov = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+            const bf16x4 ov = to_op4_unclamped<T>(v0, v1, v2, v3);
             *reinterpret_cast<bf16x4*>(slot) = ov;
           }
           if (want_mean) {  // only the last layer's outputs are averaged over the pixels (the heads' input)
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {  // results -> global, same (16 pixels x 4 chunks) blocks as the load
       if (i == 1 && !two) break;
-      __bf16* dst = a.out + (long)bimg[i] * (kPix * kCh);
+      T* dst = a.out + (long)bimg[i] * (kPix * kCh);
 #pragma unroll
       for (int j = 0; j < 72 / NW; ++j) {
         const int it = wave + NW * j;
@@ -901,10 +908,10 @@ __global__ __launch_bounds__(512, 2) void conv_chain_pair_kernel(ChainArgs a) {
   MZ_LAUNCH_END(a.n_layers);
 }
 
-template <int NW, int PF, int SPLIT>
-int launch_trunk(const TrunkArgs& a, int B, hipStream_t stream) {
+template <typename T, int NW, int PF, int SPLIT>
+int launch_trunk(const TrunkArgs<T>& a, int B, hipStream_t stream) {
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv_trunk_kernel<NW, PF, SPLIT>;
+  auto kern = conv_trunk_kernel<T, NW, PF, SPLIT>;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), kLdsTotal, configured, "conv_trunk")) return rc;
   hipLaunchKernelGGL(kern, dim3(B * SPLIT), dim3(64 * NW), kLdsTotal, stream, a);
   return mz::check_launch("mz_conv3x3_bf16 (trunk)");
@@ -928,33 +935,35 @@ extern "C" int mz_debug_read_launches(long long* host, int n) {
 }
 #endif
 
-namespace mz {
-// called by mz_conv3x3_bf16 for the 12x12x256->256 stride-1 shape
-int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
-                    const void* residual, void* out, const float* action_vec, const int32_t* actions,
-                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream, double* stats) {
-  TrunkArgs a{static_cast<const __bf16*>(in), in_slot, slot_stride, static_cast<const __bf16*>(wpk), bias,
-              static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), action_vec, actions, mean_out, relu,
-              stats};
+namespace {
+
+template <typename T>
+int conv_trunk_any(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                   const void* residual, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                   int32_t B, int32_t relu, hipStream_t stream, double* stats) {
+  TrunkArgs<T> a{static_cast<const T*>(in), in_slot, slot_stride, static_cast<const T*>(wpk), bias,
+                 static_cast<const T*>(residual), static_cast<T*>(out), action_vec, actions, mean_out, relu, stats};
   // two workgroups per image while that still leaves CUs idle otherwise
-  if (2 * B <= mz::compute_units()) return launch_trunk<8, 2, 2>(a, B, stream);
-  return launch_trunk<8, 2, 1>(a, B, stream);
+  if (2 * B <= mz::compute_units()) return launch_trunk<T, 8, 2, 2>(a, B, stream);
+  return launch_trunk<T, 8, 2, 1>(a, B, stream);
 }
-int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
-                    int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
-                    int32_t B, hipStream_t stream) {
-  ChainArgs a{};
-  a.in = static_cast<const __bf16*>(in);
+
+template <typename T>
+int conv_chain_any(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                   int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                   int32_t B, hipStream_t stream) {
+  ChainArgs<T> a{};
+  a.in = static_cast<const T*>(in);
   a.in_slot = in_slot;
   a.slot_stride = slot_stride;
-  a.out = static_cast<__bf16*>(out);
+  a.out = static_cast<T*>(out);
   a.avec = action_vec;
   a.actions = actions;
   a.mean_out = mean_out;
   a.B = B;
   a.n_layers = n_layers;
   for (int l = 0; l < n_layers; ++l) {
-    a.wpk[l] = static_cast<const __bf16*>(layers[l].wpk);
+    a.wpk[l] = static_cast<const T*>(layers[l].wpk);
     a.bias[l] = layers[l].bias;
     if (layers[l].relu) a.relu_mask |= 1u << l;
     if (layers[l].add_residual) a.res_mask |= 1u << l;
@@ -966,18 +975,45 @@ int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride,
   static const bool no_pairs = getenv("MZ_CHAIN_NO_PAIRS") != nullptr;  // kernel comparisons
   if (B > n_cu && !no_pairs) {
     static bool configured2[mz::kMaxDevices] = {false};
-    auto kern2 = conv_chain_pair_kernel<MZ_PAIR_PF>;
+    auto kern2 = conv_chain_pair_kernel<T, MZ_PAIR_PF>;
     if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern2), lds, configured2, "conv_chain_pair"))
       return rc;
     const int pairs = (B + 1) / 2;
     hipLaunchKernelGGL(kern2, dim3(pairs < n_cu ? pairs : n_cu), dim3(512), lds, stream, a);
-    return mz::check_launch("mz_conv_chain_bf16");
+    return mz::check_launch("mz_conv_chain");
   }
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv_chain_kernel<MZ_CHAIN_NW, MZ_CHAIN_PF>;
+  auto kern = conv_chain_kernel<T, MZ_CHAIN_NW, MZ_CHAIN_PF>;
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain")) return rc;
   const int grid = B < n_cu ? B : n_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MZ_CHAIN_NW), lds, stream, a);
-  return mz::check_launch("mz_conv_chain_bf16");
+  return mz::check_launch("mz_conv_chain");
+}
+
+}  // namespace
+
+namespace mz {
+// called by mz_conv3x3_bf16 / mz_conv3x3_f16 for the 12x12x256->256 stride-1 shape (half: operands in IEEE half)
+int conv_trunk_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                    const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                    float* mean_out, int32_t B, int32_t relu, hipStream_t stream, double* stats) {
+  return conv_trunk_any<__bf16>(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B, relu,
+                                stream, stats);
+}
+int conv_trunk_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const void* wpk, const float* bias,
+                   const void* residual, void* out, const float* action_vec, const int32_t* actions,
+                   float* mean_out, int32_t B, int32_t relu, hipStream_t stream) {
+  return conv_trunk_any<_Float16>(in, in_slot, slot_stride, wpk, bias, residual, out, action_vec, actions, mean_out, B,
+                                  relu, stream, nullptr);
+}
+int conv_chain_bf16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                    int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                    int32_t B, hipStream_t stream) {
+  return conv_chain_any<__bf16>(in, in_slot, slot_stride, layers, n_layers, out, action_vec, actions, mean_out, B, stream);
+}
+int conv_chain_f16(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                   int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                   int32_t B, hipStream_t stream) {
+  return conv_chain_any<_Float16>(in, in_slot, slot_stride, layers, n_layers, out, action_vec, actions, mean_out, B, stream);
 }
 }  // namespace mz

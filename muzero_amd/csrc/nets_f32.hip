@@ -225,13 +225,30 @@ __device__ __forceinline__ void dense16(const float* __restrict__ wp, const floa
   }
 }
 
-// the same layer on the bf16 matrix cores (throughput precision): weights are bf16 fragments
+// the same layer on the matrix cores with 16-bit operands (T = __bf16: the throughput precision; T = _Float16:
+// IEEE half, three more significant bits at the same rate): weights are fragments
 // [out tile][K/32][lane][8] (lane l: W[tile*16 + l%16][32*kstep + 8*(l/16) + j]); the 16
 // samples are converted from the float32 LDS copy on the fly; float32 accumulation
-typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, const float* __restrict__ bias,
+template <typename T> using hvec8 = T __attribute__((ext_vector_type(8)));
+template <typename T> using hvec4 = T __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 head_mfma(hvec8<__bf16> a, hvec8<__bf16> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 head_mfma(hvec8<_Float16> a, hvec8<_Float16> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// float32 -> operand format (nearest even; IEEE half saturates at its largest finite value)
+template <typename T> __device__ __forceinline__ T head_op(float v);
+template <> __device__ __forceinline__ __bf16 head_op<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 head_op<_Float16>(float v) {
+  return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+}
+
+template <typename T>
+__device__ __forceinline__ void dense16_bf16(const hvec8<T>* __restrict__ wp, const float* __restrict__ bias,
                                              const float* src, int lds, float* dst, int ldd, int K, int tiles,
                                              bool relu) {
+  typedef hvec8<T> hbf16x8;
   constexpr int NW = kHeadsBlock / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ks_n = K / 32;
@@ -242,8 +259,8 @@ __device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, con
     for (int ks = 0; ks < ks_n; ++ks) {
       hbf16x8 bfrag;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bfrag[j] = (__bf16)sp[ks * 32 + j];
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(long)ks * 64], bfrag, acc, 0, 0, 0);
+      for (int j = 0; j < 8; ++j) bfrag[j] = head_op<T>(sp[ks * 32 + j]);
+      acc = head_mfma(w[(long)ks * 64], bfrag, acc);
     }
     const int o = t * 16 + (lane >> 4) * 4;
     const float4 bv = *reinterpret_cast<const float4*>(bias + o);
@@ -258,13 +275,13 @@ __device__ __forceinline__ void dense16_bf16(const hbf16x8* __restrict__ wp, con
 
 // The weight fragments of a whole output tile (K = 32*KS), requested in one go: the kernel is bound by the
 // latency of its dependent phases, so a tile's fragments are loaded before the data they multiply exists.
-template <int KS>
+template <typename T, int KS>
 struct TileFrags {
-  hbf16x8 f[KS];
+  hvec8<T> f[KS];
 };
-template <int KS>
-__device__ __forceinline__ void load_tile_frags(TileFrags<KS>& fr, const hbf16x8* __restrict__ wp, int t) {
-  const hbf16x8* w = wp + (long)t * KS * 64 + (threadIdx.x & 63);
+template <typename T, int KS>
+__device__ __forceinline__ void load_tile_frags(TileFrags<T, KS>& fr, const hvec8<T>* __restrict__ wp, int t) {
+  const hvec8<T>* w = wp + (long)t * KS * 64 + (threadIdx.x & 63);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) fr.f[ks] = w[ks * 64];
 }
@@ -274,23 +291,24 @@ __device__ __forceinline__ void load_tile_frags(TileFrags<KS>& fr, const hbf16x8
 // bf16 once when they are written gives the same values as rounding them at every read, and re-reading the
 // float32 image - 64 four-byte reads per lane and tile - was what the layers spent their time on).
 constexpr int kActPitch = 256 * 2 + 16;  // bytes per sample: 33 units of 16 bytes, so 16 rows fall on 16 bank groups
-template <int KS, bool TO_BF16>
-__device__ __forceinline__ void dense16_tile(const TileFrags<KS>& fr, const float4 bv, const char* src, char* dst_act,
+template <typename T, int KS, bool TO_BF16>
+__device__ __forceinline__ void dense16_tile(const TileFrags<T, KS>& fr, const float4 bv, const char* src, char* dst_act,
                                              float* dst, int ldd, int t, bool relu) {
+  typedef hvec8<T> hbf16x8;
   const int lane = threadIdx.x & 63;
   const char* sp = src + (lane & 15) * kActPitch + (lane >> 4) * 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr.f[ks], *reinterpret_cast<const hbf16x8*>(sp + ks * 64), acc, 0, 0, 0);
+    acc = head_mfma(fr.f[ks], *reinterpret_cast<const hbf16x8*>(sp + ks * 64), acc);
   float v0 = acc[0] + bv.x, v1 = acc[1] + bv.y, v2 = acc[2] + bv.z, v3 = acc[3] + bv.w;
   if (relu) {
     v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
   }
   const int o = t * 16 + (lane >> 4) * 4;
   if constexpr (TO_BF16) {
-    typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<hbf16x4*>(dst_act + (lane & 15) * kActPitch + o * 2) = hbf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+    *reinterpret_cast<hvec4<T>*>(dst_act + (lane & 15) * kActPitch + o * 2) =
+        hvec4<T>{head_op<T>(v0), head_op<T>(v1), head_op<T>(v2), head_op<T>(v3)};
   } else {
     float* d = dst + (lane & 15) * ldd + o;
     d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
@@ -303,9 +321,9 @@ __device__ __forceinline__ void dense16_any(const float* wp, const float* bias, 
   else dense16<1>(wp, bias, src, lds, dst, ldd, K, tiles, relu);
 }
 
-// FAST: every head has bf16 weights, C == Hd == 256 and at most 48 output tiles (checked by the host), so the
-// kernel holds only that path's registers.
-template <bool FAST>
+// FAST: every head has 16-bit weights of format T, C == Hd == 256 and at most 48 output tiles (checked by the
+// host), so the kernel holds only that path's registers.
+template <bool FAST, typename T = __bf16>
 __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     const float* __restrict__ mean, int B, int C, int Hd, int A, HeadW pol, HeadW val, HeadW rew,
     float* __restrict__ priors, float* __restrict__ value, float* __restrict__ reward,
@@ -334,7 +352,8 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     char* h_s = smem + kHeadSamples * kActPitch;
     logit_s = reinterpret_cast<float*>(smem + 2 * kHeadSamples * kActPitch);
     const int wv = threadIdx.x >> 6, lq = (threadIdx.x & 63) >> 4;
-    TileFrags<8> fa, fb;
+    typedef hvec8<T> hbf16x8;   // eight weights / activations of format T
+    TileFrags<T, 8> fa, fb;
     const hbf16x8* w2 = reinterpret_cast<const hbf16x8*>(hw.w2p);
     // Every load below is unconditional (sample and tile indices are clamped instead): a load inside a branch
     // makes the compiler wait for ALL outstanding loads where the branch rejoins, and the barrier would then
@@ -344,25 +363,25 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     {
       const int s = threadIdx.x >> 6, k = (threadIdx.x & 63) * 4;
       float4 m = *reinterpret_cast<const float4*>(mean + (long)(b0 + (s < ns ? s : ns - 1)) * 256 + k);
-      load_tile_frags<8>(fa, reinterpret_cast<const hbf16x8*>(hw.w1p), wv);
+      load_tile_frags<T, 8>(fa, reinterpret_cast<const hbf16x8*>(hw.w1p), wv);
       if (s >= ns) m = float4{0.f, 0.f, 0.f, 0.f};
-      typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
-      *reinterpret_cast<hbf16x4*>(x_s + s * kActPitch + k * 2) = hbf16x4{(__bf16)m.x, (__bf16)m.y, (__bf16)m.z, (__bf16)m.w};
+      *reinterpret_cast<hvec4<T>*>(x_s + s * kActPitch + k * 2) =
+          hvec4<T>{head_op<T>(m.x), head_op<T>(m.y), head_op<T>(m.z), head_op<T>(m.w)};
     }
     __builtin_amdgcn_sched_barrier(0);
     const float4 bv1 = *reinterpret_cast<const float4*>(hw.b1 + wv * 16 + lq * 4);
-    load_tile_frags<8>(fb, w2, ta);
+    load_tile_frags<T, 8>(fb, w2, ta);
     const float4 bv2a = *reinterpret_cast<const float4*>(hw.b2 + ta * 16 + lq * 4);
     const float4 bv2b = *reinterpret_cast<const float4*>(hw.b2 + tb * 16 + lq * 4);
     const float4 bv2c = *reinterpret_cast<const float4*>(hw.b2 + tc * 16 + lq * 4);
     __syncthreads();
-    dense16_tile<8, true>(fa, bv1, x_s, h_s, nullptr, 0, wv, true);
-    load_tile_frags<8>(fa, w2, tb);
+    dense16_tile<T, 8, true>(fa, bv1, x_s, h_s, nullptr, 0, wv, true);
+    load_tile_frags<T, 8>(fa, w2, tb);
     __syncthreads();
-    if (wv < otiles) dense16_tile<8, false>(fb, bv2a, h_s, nullptr, logit_s, ldo, wv, false);
-    load_tile_frags<8>(fb, w2, tc);
-    if (wv + NW < otiles) dense16_tile<8, false>(fa, bv2b, h_s, nullptr, logit_s, ldo, wv + NW, false);
-    if (wv + 2 * NW < otiles) dense16_tile<8, false>(fb, bv2c, h_s, nullptr, logit_s, ldo, wv + 2 * NW, false);
+    if (wv < otiles) dense16_tile<T, 8, false>(fb, bv2a, h_s, nullptr, logit_s, ldo, wv, false);
+    load_tile_frags<T, 8>(fb, w2, tc);
+    if (wv + NW < otiles) dense16_tile<T, 8, false>(fa, bv2b, h_s, nullptr, logit_s, ldo, wv + NW, false);
+    if (wv + 2 * NW < otiles) dense16_tile<T, 8, false>(fb, bv2c, h_s, nullptr, logit_s, ldo, wv + 2 * NW, false);
     __syncthreads();
   } else {
   for (int i = threadIdx.x; i < kHeadSamples * C; i += kHeadsBlock) {
@@ -370,10 +389,12 @@ __global__ __launch_bounds__(kHeadsBlock) void heads_kernel(
     mean_s[s * ldm + k] = s < ns ? mean[(long)(b0 + s) * C + k] : 0.f;
   }
   __syncthreads();
-  if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  if (hw.bf16 == 1) dense16_bf16<__bf16>(reinterpret_cast<const hvec8<__bf16>*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
+  else if (hw.bf16 == 2) dense16_bf16<_Float16>(reinterpret_cast<const hvec8<_Float16>*>(hw.w1p), hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   else dense16_any(hw.w1p, hw.b1, mean_s, ldm, hid_s, ldh, C, Hd / 16, true);
   __syncthreads();
-  if (hw.bf16) dense16_bf16(reinterpret_cast<const hbf16x8*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  if (hw.bf16 == 1) dense16_bf16<__bf16>(reinterpret_cast<const hvec8<__bf16>*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
+  else if (hw.bf16 == 2) dense16_bf16<_Float16>(reinterpret_cast<const hvec8<_Float16>*>(hw.w2p), hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   else dense16_any(hw.w2p, hw.b2, hid_s, ldh, logit_s, ldo, Hd, otiles, false);
   __syncthreads();
   }
@@ -485,7 +506,7 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
   MZ_REQUIRE(B > 0 && A >= 1 && A <= MZ_MAX_ACTIONS && S >= 1, "mz_heads: bad sizes");
   MZ_REQUIRE(C > 0 && C % 4 == 0 && Hd > 0 && Hd % 16 == 0, "mz_heads: C must be a multiple of 4 and Hd of 16");
   for (const mz_head_weights* h : {policy, value_w, reward_w})
-    MZ_REQUIRE(!h || !h->bf16 || (C % 32 == 0 && Hd % 32 == 0), "mz_heads: bf16 weights need C and Hd multiples of 32");
+    MZ_REQUIRE(!h || !h->bf16 || (C % 32 == 0 && Hd % 32 == 0), "mz_heads: 16-bit weights need C and Hd multiples of 32");
   const int O = 2 * S + 1;
   const int omax = ((O > A ? O : A) + 15) / 16 * 16;
   const size_t lds = (size_t)kHeadSamples * ((Hd + 1) + (C > omax ? C + 1 : omax + 1)) * sizeof(float);
@@ -497,12 +518,20 @@ int mz_heads(const float* mean, int32_t B, int32_t C, int32_t Hd, int32_t A, int
   };
   bool fast = C == 256 && Hd == 256 && (O + 15) / 16 <= 3 * (kHeadsBlock / 64) &&
               reinterpret_cast<uintptr_t>(mean) % 16 == 0;
-  for (const mz_head_weights* h : {policy, value_w, reward_w}) fast = fast && (!h || h->bf16);
+  const int fmt = policy->bf16;   // 0 float32, 1 bf16, 2 IEEE half; the fast kernel wants one 16-bit format throughout
+  for (const mz_head_weights* h : {policy, value_w, reward_w}) {
+    MZ_REQUIRE(!h || (h->bf16 >= 0 && h->bf16 <= 2), "mz_heads: weight format must be 0 (float32), 1 (bf16) or 2 (half)");
+    fast = fast && (!h || (h->bf16 != 0 && h->bf16 == fmt));
+  }
   const dim3 grid((B + kHeadSamples - 1) / kHeadSamples, reward_w ? 3 : 2);
   const size_t fast_lds = (size_t)kHeadSamples * (2 * kActPitch + (omax + 1) * sizeof(float));
-  if (fast)
-    hipLaunchKernelGGL(heads_kernel<true>, grid, dim3(kHeadsBlock), fast_lds, mz::as_stream(stream), mean, B, C, Hd, A,
-                       cvt(policy, A), cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits,
+  if (fast && fmt == 2)
+    hipLaunchKernelGGL((heads_kernel<true, _Float16>), grid, dim3(kHeadsBlock), fast_lds, mz::as_stream(stream), mean, B, C,
+                       Hd, A, cvt(policy, A), cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits,
+                       value_logits, reward_logits);
+  else if (fast)
+    hipLaunchKernelGGL((heads_kernel<true, __bf16>), grid, dim3(kHeadsBlock), fast_lds, mz::as_stream(stream), mean, B, C,
+                       Hd, A, cvt(policy, A), cvt(value_w, O), cvt(reward_w, O), priors, value, reward, policy_logits,
                        value_logits, reward_logits);
   else
     hipLaunchKernelGGL(heads_kernel<false>, grid, dim3(kHeadsBlock), lds, mz::as_stream(stream), mean, B, C, Hd, A,

@@ -10,6 +10,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
   unsigned int u = __float_as_uint(f);  // finite, non-negative inputs only
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
+// a pixel value in [0, 1] as a 16-bit pattern: bf16, or IEEE half when HALF (both round to nearest even)
+template <bool HALF>
+__device__ __forceinline__ unsigned short f32_to_16(float f) {
+  if constexpr (HALF) return __builtin_bit_cast(unsigned short, (_Float16)f);
+  else return f32_to_bf16_rne(f);
+}
 
 // ring [B][D][frame_bytes]; frames [B][frame_bytes].  fill_all != 0 copies the
 // frame into every slot (the reset rule, train.py:49-50).
@@ -35,7 +41,7 @@ __global__ void ring_push_kernel(unsigned char* __restrict__ ring, const unsigne
 // first (train.py:62-63), normalised by /255 in float32 (bit-identical to the
 // reference's float64 divide + float32 cast for every byte value).
 constexpr int kPix = 64;
-template <typename OutT>
+template <typename OutT, bool HALF = false>
 __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* __restrict__ ring,
                                                          OutT* __restrict__ out, int D, int HW, int newest) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* _
     const int px = i / C, c = i % C;
     const float v = (float)st[(c / 3) * row + px * 3 + (c % 3)] / 255.0f;
     const long o = ((long)b * HW + p0 + px) * C + c;
-    if constexpr (sizeof(OutT) == 2) out[o] = f32_to_bf16_rne(v);
+    if constexpr (sizeof(OutT) == 2) out[o] = f32_to_16<HALF>(v);
     else out[o] = v;
   }
 }
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* _
 // number of memory instructions, not by bytes).
 // SPLIT: OutT is bf16 and the output is the (hi, lo) pair layout [B][2][HW][C] of the bf16x3 precision:
 // hi = bf16(v), lo = bf16(v - hi).
-template <typename OutT, bool SPLIT = false>
+template <typename OutT, bool SPLIT = false, bool HALF = false>
 __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned char* __restrict__ ring,
                                                              OutT* __restrict__ out, int D, int HW, int newest) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,10 +108,10 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
                                                         lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
     } else if constexpr (sizeof(OutT) == 2) {
       uint4 pk;
-      pk.x = f32_to_bf16_rne(v[0]) | ((unsigned)f32_to_bf16_rne(v[1]) << 16);
-      pk.y = f32_to_bf16_rne(v[2]) | ((unsigned)f32_to_bf16_rne(v[3]) << 16);
-      pk.z = f32_to_bf16_rne(v[4]) | ((unsigned)f32_to_bf16_rne(v[5]) << 16);
-      pk.w = f32_to_bf16_rne(v[6]) | ((unsigned)f32_to_bf16_rne(v[7]) << 16);
+      pk.x = f32_to_16<HALF>(v[0]) | ((unsigned)f32_to_16<HALF>(v[1]) << 16);
+      pk.y = f32_to_16<HALF>(v[2]) | ((unsigned)f32_to_16<HALF>(v[3]) << 16);
+      pk.z = f32_to_16<HALF>(v[4]) | ((unsigned)f32_to_16<HALF>(v[5]) << 16);
+      pk.w = f32_to_16<HALF>(v[6]) | ((unsigned)f32_to_16<HALF>(v[7]) << 16);
       *reinterpret_cast<uint4*>(out + o) = pk;
     } else {
       *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
 // values of its unit - halo pixel, tile pixels or zero padding - and writes them with one 16-byte store, so
 // the lanes of a wavefront cover whole runs with consecutive addresses.
 constexpr int kRotRun = 56;
-template <typename OutT>
+template <typename OutT, bool HALF = false>
 __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char* __restrict__ frames,
                                                             OutT* __restrict__ obs, int D, int HW, int W, int slot,
                                                             int fill_all, const int* __restrict__ fill_mask) {
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void obs_slot_write_kernel(const unsigned char
   for (int j = 0; j < V; ++j) {
     const int e = u * V + j;
     const float x = (e < 51 && !(first_in_row && e < 3)) ? (float)raw[j] / 255.0f : 0.f;
-    if constexpr (sizeof(OutT) == 2) v[j] = f32_to_bf16_rne(x);
+    if constexpr (sizeof(OutT) == 2) v[j] = f32_to_16<HALF>(x);
     else v[j] = x;
   }
   uint4 pk;
@@ -231,7 +237,17 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
   const size_t lds = (size_t)D * kPix * 3;
   MZ_REQUIRE(lds <= 64 * 1024, "mz_ring_to_obs: ring depth %d too large", D);
   const dim3 grid((HW + kPix - 1) / kPix, B);
-  MZ_REQUIRE(out_is_bf16 >= 0 && out_is_bf16 <= 2, "mz_ring_to_obs: output format must be 0 (float32), 1 (bf16) or 2 (pairs)");
+  MZ_REQUIRE(out_is_bf16 >= 0 && out_is_bf16 <= 3,
+             "mz_ring_to_obs: output format must be 0 (float32), 1 (bf16), 2 (bf16 pairs) or 3 (half)");
+  if (out_is_bf16 == 3) {
+    if ((3 * D) % 8 == 0 && HW % kPix == 0)
+      hipLaunchKernelGGL((ring_to_obs_vec_kernel<unsigned short, false, true>), grid, dim3(256), lds, mz::as_stream(stream),
+                         ring, static_cast<unsigned short*>(out), D, HW, newest_slot);
+    else
+      hipLaunchKernelGGL((ring_to_obs_kernel<unsigned short, true>), grid, dim3(256), lds, mz::as_stream(stream), ring,
+                         static_cast<unsigned short*>(out), D, HW, newest_slot);
+    return mz::check_launch("mz_ring_to_obs");
+  }
   if (out_is_bf16 == 2) {
     MZ_REQUIRE((3 * D) % 8 == 0 && HW % kPix == 0, "mz_ring_to_obs: the pair format needs 3*D %% 8 == 0 and HW %% 64 == 0");
     hipLaunchKernelGGL((ring_to_obs_vec_kernel<unsigned short, true>), grid, dim3(256), lds, mz::as_stream(stream), ring,
@@ -263,9 +279,14 @@ int mz_obs_slot_write(const uint8_t* frames, void* obs, int32_t out_is_bf16, int
   MZ_REQUIRE(slot >= 0 && slot < D, "mz_obs_slot_write: slot %d outside a stack of depth %d", slot, D);
   const int HW = H * W;
   MZ_REQUIRE((uintptr_t)obs % 16 == 0, "mz_obs_slot_write: obs must be 16-byte aligned");
+  MZ_REQUIRE(out_is_bf16 == 0 || out_is_bf16 == 1 || out_is_bf16 == 3,
+             "mz_obs_slot_write: output format must be 0 (float32), 1 (bf16) or 3 (half)");
   const int units = (HW / 16) * (out_is_bf16 ? 7 : 14);   // 16-byte units of one slot's runs per game
   const dim3 grid((units + 255) / 256, B);
-  if (out_is_bf16)
+  if (out_is_bf16 == 3)
+    hipLaunchKernelGGL((obs_slot_write_kernel<unsigned short, true>), grid, dim3(256), 0, mz::as_stream(stream), frames,
+                       static_cast<unsigned short*>(obs), D, HW, W, slot, fill_all, fill_mask);
+  else if (out_is_bf16)
     hipLaunchKernelGGL(obs_slot_write_kernel<unsigned short>, grid, dim3(256), 0, mz::as_stream(stream), frames,
                        static_cast<unsigned short*>(obs), D, HW, W, slot, fill_all, fill_mask);
   else

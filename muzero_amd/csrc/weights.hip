@@ -24,7 +24,8 @@ struct PackArgs {
   const float* var;
   double eps;
   int Cout, Cin, chunk;
-  int mode;       // 0 bf16 fragments of w; 1 bf16 fragments of w - bf16(w); 2 float32 [tap][Cin][Cout]
+  int mode;       // 0 bf16 fragments of w; 1 bf16 fragments of w - bf16(w); 2 float32 [tap][Cin][Cout];
+                  // 3 IEEE-half fragments of w (same order as 0)
   int transpose;  // data-gradient form: out channel <-> in channel, taps mirrored
   int rot_depth;  // > 0: n_copies = rot_depth copies with the input channels rotated by frame slot
   void* out;
@@ -79,8 +80,12 @@ __device__ __forceinline__ void pack_fragments(const PackArgs& a, int copy, long
     int ci = cj;
     if (a.rot_depth > 0) ci = ((cj / 3 - copy - 1 + 2 * a.rot_depth) % a.rot_depth) * 3 + cj % 3;
     const float f = folded_weight(a, co, ci, tap);
-    const __bf16 hi = (__bf16)f;
-    out[unit * 8 + j] = a.mode == 0 ? hi : (__bf16)(f - (float)hi);
+    if (a.mode == 3) {   // round to nearest even; beyond the largest finite half: saturate
+      reinterpret_cast<_Float16*>(out)[unit * 8 + j] = (_Float16)fminf(fmaxf(f, -65504.f), 65504.f);
+    } else {
+      const __bf16 hi = (__bf16)f;
+      out[unit * 8 + j] = a.mode == 0 ? hi : (__bf16)(f - (float)hi);
+    }
   }
 }
 
@@ -139,12 +144,14 @@ __global__ void pack_linear_kernel(const float* __restrict__ w, const float* __r
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)tiles * 16 * K;
   if (i < total) {
-    if (bf16) {  // [(t*(K/32) + ks)*64 + lane][j] = W[t*16 + lane%16][32*ks + 8*(lane/16) + j]
+    if (bf16) {  // [(t*(K/32) + ks)*64 + lane][j] = W[t*16 + lane%16][32*ks + 8*(lane/16) + j]; bf16 == 2: IEEE half
       const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
       const long r = i >> 9;
       const int ks = (int)(r % (K / 32)), t = (int)(r / (K / 32));
       const int row = t * 16 + (lane & 15), col = 32 * ks + 8 * (lane >> 4) + j;
-      reinterpret_cast<__bf16*>(wp)[i] = (__bf16)(row < O ? w[(long)row * K + col] : 0.f);
+      const float x = row < O ? w[(long)row * K + col] : 0.f;
+      if (bf16 == 2) reinterpret_cast<_Float16*>(wp)[i] = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+      else reinterpret_cast<__bf16*>(wp)[i] = (__bf16)x;
     } else {     // [(t*(K/4) + ks)*64 + lane] = W[t*16 + lane%16][4*ks + lane/16]
       const int lane = (int)(i & 63);
       const long r = i >> 6;
@@ -180,7 +187,8 @@ int mz_weights_fold_pack(const float* w, const float* conv_bias, const float* bn
                          int32_t cin_chunk, int32_t mode, int32_t transpose, int32_t rot_depth, void* out,
                          float* bias_out, mz_stream_t stream) {
   MZ_REQUIRE(w && out && Cout > 0 && Cin > 0, "mz_weights_fold_pack: null tensor or empty shape");
-  MZ_REQUIRE(mode >= 0 && mode <= 2, "mz_weights_fold_pack: mode must be 0 (bf16), 1 (bf16 residue) or 2 (float32)");
+  MZ_REQUIRE(mode >= 0 && mode <= 3,
+             "mz_weights_fold_pack: mode must be 0 (bf16), 1 (bf16 residue), 2 (float32) or 3 (half)");
   const bool bn = bn_weight || bn_bias || bn_mean || bn_var;
   MZ_REQUIRE(!bn || (bn_weight && bn_bias && bn_mean && bn_var), "mz_weights_fold_pack: BatchNorm needs all four vectors");
   MZ_REQUIRE(!(transpose && (bn || Cin != Cout || rot_depth)),
@@ -227,6 +235,7 @@ int mz_weights_pack_many(const float* const* w, void* const* out, const int32_t*
 int mz_pack_linear(const float* w, const float* bias, int32_t O, int32_t K, int32_t bf16, void* w_packed,
                    float* bias_padded, mz_stream_t stream) {
   MZ_REQUIRE(w && w_packed && O > 0 && K > 0, "mz_pack_linear: null tensor or empty shape");
+  MZ_REQUIRE(bf16 >= 0 && bf16 <= 2, "mz_pack_linear: format must be 0 (float32), 1 (bf16) or 2 (half)");
   MZ_REQUIRE(K % (bf16 ? 32 : 4) == 0, "mz_pack_linear: K = %d must be a multiple of %d", K, bf16 ? 32 : 4);
   MZ_REQUIRE((bias != nullptr) == (bias_padded != nullptr), "mz_pack_linear: bias and bias_padded go together");
   const long total = (long)((O + 15) / 16) * 16 * K;

@@ -20,15 +20,15 @@ def packed_elems(cout: int, cin: int) -> int:
     return cout * cin * 9 + 2 * (cout // 16) * 512
 
 
-def pack_weights(w: torch.Tensor, chunk: int) -> torch.Tensor:
-    """w: float32 [Cout][Cin][3][3] (BatchNorm already folded) -> bf16 fragments
+def pack_weights(w: torch.Tensor, chunk: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """w: float32 [Cout][Cin][3][3] (BatchNorm already folded) -> fragments of ``dtype`` (bfloat16 or float16)
     [cin_chunk][tap][k32][n16][lane = kq*16 + r][8], padded by two k-steps of zeros."""
     cout, cin = w.shape[0], w.shape[1]
     ncc, kc, nt = cin // chunk, chunk // 32, cout // 16
-    x = w.to(torch.bfloat16).permute(2, 3, 1, 0).reshape(9, ncc, kc, 4, 8, nt, 16)
+    x = w.to(dtype).permute(2, 3, 1, 0).reshape(9, ncc, kc, 4, 8, nt, 16)
     #    dims:  tap, cc, kc, kq, j, nt, r   ->   cc, tap, kc, nt, kq, r, j
     x = x.permute(1, 0, 2, 5, 3, 6, 4).contiguous().view(-1)
-    pad = torch.zeros(2 * nt * 512, dtype=torch.bfloat16)
+    pad = torch.zeros(2 * nt * 512, dtype=dtype)
     return torch.cat([x, pad])
 
 
@@ -43,10 +43,12 @@ def pack_weights_batch(w: torch.Tensor, chunk: int) -> torch.Tensor:
     return torch.cat([x, pad], dim=1).contiguous()
 
 
-def conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride, action_vec, actions, mean_out, weights=None):
-    """weights: packed fragments to use instead of the layer's own (same shape, e.g. permuted input channels)."""
+def conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride, action_vec, actions, mean_out, weights=None,
+         half=False):
+    """weights: packed fragments to use instead of the layer's own (same shape, e.g. permuted input channels).
+    half: activations and fragments are IEEE half (mz_conv3x3_f16) instead of bf16."""
     weights = layer.dev["w"] if weights is None else weights
-    _lib.call("mz_conv3x3_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(weights),
+    _lib.call("mz_conv3x3_f16" if half else "mz_conv3x3_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, _lib.ptr(weights),
               _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out), _lib.ptr(action_vec),
               _lib.ptr(actions), _lib.ptr(mean_out), B, H, W, layer.cin, layer.cout, layer.stride,
               1 if relu else 0, _lib.current_stream())

@@ -14,7 +14,10 @@ are the reference's, so a reference checkpoint's ``model_state_dict`` loads
 directly.
 
 Precisions: ``"bf16"`` - bf16 MFMA kernels with float32 accumulation for the reference's
-default architecture (throughput); ``"bf16x3"`` - the same architecture with every float32 value
+default architecture (throughput); ``"f16"`` - the same kernels with operands in IEEE half (11 significant
+bits instead of 8, the same matrix rate: the policy / value / reward outputs land within the 1e-3 bound of the
+reference's float32 path on its fixtures, hidden states within ~0.5 % of their RMS; values beyond 65 504
+saturate); ``"bf16x3"`` - the same architecture with every float32 value
 carried as a (hi, lo) pair of bf16 values and three MFMAs per product: float32-accurate outputs
 (1e-3 against the reference's float32 path) at a third of the bf16 matrix rate; ``"fp32"`` - exact
 float32 kernels on the vector units for any layer shape (validation).
@@ -144,7 +147,8 @@ class Head:
     """One fully connected head with a single hidden layer; its weights live in persistent device
     buffers in MFMA fragment order (``mz_pack_linear`` refills them in place)."""
 
-    def __init__(self, sd, name: str, device, bf16: bool = False):
+    def __init__(self, sd, name: str, device, bf16: int = 0):
+        """bf16: weight format - 0 float32, 1 bf16, 2 IEEE half (mz_head_weights.bf16)."""
         keys = sorted({int(k.split(".")[-2]) for k in sd if k.startswith(name + ".") and k.endswith(".weight")})
         if len(keys) != 2:
             raise NotImplementedError(f"{name}: exactly one hidden layer is supported (got {len(keys) - 1})")
@@ -153,15 +157,15 @@ class Head:
         self.hidden, self.out, self.cin = int(w1.shape[0]), int(w2.shape[0]), int(w1.shape[1])
         if self.hidden % 16 or self.cin % 4:
             raise NotImplementedError(f"{name}: hidden width must be a multiple of 16 and the input of 4")
-        self.bf16 = bool(bf16 and self.hidden % 32 == 0 and self.cin % 32 == 0)
-        dt = torch.bfloat16 if self.bf16 else torch.float32
+        self.bf16 = int(bf16) if (bf16 and self.hidden % 32 == 0 and self.cin % 32 == 0) else 0
+        dt = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[self.bf16]
         tiles = (self.out + 15) // 16
         self.w1p = torch.empty(self.hidden * self.cin, dtype=dt, device=device)
         self.b1 = torch.empty(self.hidden, dtype=torch.float32, device=device)
         self.w2p = torch.empty(tiles * 16 * self.hidden, dtype=dt, device=device)
         self.b2 = torch.empty(tiles * 16, dtype=torch.float32, device=device)
         self.c = _HeadWeights(self.w1p.data_ptr(), self.b1.data_ptr(), self.w2p.data_ptr(), self.b2.data_ptr(),
-                              1 if self.bf16 else 0, 0)
+                              self.bf16, 0)
 
     def fill(self, dsd) -> None:
         """dsd: the state_dict as float32 device tensors."""
@@ -179,15 +183,17 @@ class Head:
 class MuZeroNetwork:
     def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0,
                  input_hw=(96, 96)):
-        if precision not in ("bf16", "bf16x3", "fp32"):
-            raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
+        if precision not in ("bf16", "f16", "bf16x3", "fp32"):
+            raise ValueError("precision must be 'bf16', 'f16', 'bf16x3' or 'fp32'")
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.config = config
         self.precision = precision
         self.device = torch.device(device)
         self.split = precision == "bf16x3"     # activations are (hi, lo) bf16 pairs: [B, 2, H, W, C]
-        self.act_dtype = torch.float32 if precision == "fp32" else torch.bfloat16
-        self.obs_dtype = torch.bfloat16 if precision == "bf16" else torch.float32   # what represent() takes
+        self.half = precision == "f16"         # 16-bit operands in IEEE half instead of bf16
+        self.act_dtype = {"fp32": torch.float32, "f16": torch.float16}.get(precision, torch.bfloat16)
+        self.obs_dtype = {"bf16": torch.bfloat16, "f16": torch.float16}.get(precision, torch.float32)   # what represent() takes
+        self.op16 = precision in ("bf16", "f16")   # one 16-bit value per activation: the throughput kernels
         self.A = config.action_space_size
         self.S = config.support_size
         self.W = config.num_channels
@@ -244,7 +250,7 @@ class MuZeroNetwork:
         self.dyn_first = ConvLayer(sd, "dynamics.conv_state", "dynamics.bn", 1)
         self.dyn_blocks = [self._res(sd, f"dynamics.resblocks.{j}") for j in range(cfg.num_blocks)]
         self.action_vec = torch.empty(self.A, self.W, dtype=torch.float32, device=self.device)     # [A][W]
-        hb = self.precision == "bf16"  # heads follow the network's precision
+        hb = {"bf16": 1, "f16": 2}.get(self.precision, 0)  # heads follow the network's precision
         self.policy = Head(sd, "prediction.policy_head", self.device, hb)
         self.value_head = Head(sd, "prediction.value_head", self.device, hb)
         self.reward_head = Head(sd, "dynamics.reward_head", self.device, hb)
@@ -268,7 +274,7 @@ class MuZeroNetwork:
                 layer.chunk, layer.whole_image = mfma.kernel_info(layer.hw[0], layer.hw[1], layer.cin, layer.cout,
                                                                   layer.stride)
                 n = mfma.packed_elems(layer.cout, layer.cin)
-                layer.dev["w"] = torch.empty(n, dtype=torch.bfloat16, device=self.device)
+                layer.dev["w"] = torch.empty(n, dtype=torch.float16 if self.half else torch.bfloat16, device=self.device)
                 if self.split:   # the part of the float32 weight its bf16 rounding leaves out
                     layer.dev["w_lo"] = torch.empty(n, dtype=torch.bfloat16, device=self.device)
 
@@ -283,18 +289,22 @@ class MuZeroNetwork:
     def _fill(self) -> None:
         """Device copies of the folded weights in the layout the kernels read, into the existing buffers."""
         for layer in self.all_convs():
-            self._fold_pack(layer, 2 if self.precision == "fp32" else 0, layer.dev["w"], layer.dev["bias"])
+            self._fold_pack(layer, self._pack_mode, layer.dev["w"], layer.dev["bias"])
             if self.split:
                 self._fold_pack(layer, 1, layer.dev["w_lo"])
             if "rot" in layer.dev:
-                self._fold_pack(layer, 2 if self.precision == "fp32" else 0, layer.dev["rot"], None,
-                                rot_depth=layer.cin // 3)
+                self._fold_pack(layer, self._pack_mode, layer.dev["rot"], None, rot_depth=layer.cin // 3)
         d = self._dsd
         _lib.call("mz_action_vectors", _lib.ptr(d["dynamics.conv_action.weight"]),
                   _lib.ptr(d["dynamics.conv_action.bias"]), self.W, self.A, _lib.ptr(self.action_vec),
                   _lib.current_stream())
         for head in (self.policy, self.value_head, self.reward_head):
             head.fill(d)
+
+    @property
+    def _pack_mode(self) -> int:
+        """mz_weights_fold_pack mode of this precision's main weight buffers."""
+        return {"fp32": 2, "f16": 3}.get(self.precision, 0)
 
     @staticmethod
     def _res(sd, p):
@@ -352,11 +362,11 @@ class MuZeroNetwork:
         else:
             from . import mfma
             mfma.conv(layer, x, out, B, H, W, relu, residual, in_slot, slot_stride,
-                      self.action_vec if actions is not None else None, actions, mean_out, weights)
+                      self.action_vec if actions is not None else None, actions, mean_out, weights, half=self.half)
 
     def _chain_ok(self, convs, H, W) -> bool:
         """True when the fused LDS-resident chain kernel serves these layers."""
-        return (self.precision in ("bf16", "bf16x3") and H == 12 and W == 12 and 1 <= len(convs) <= 20
+        return (self.precision in ("bf16", "f16", "bf16x3") and H == 12 and W == 12 and 1 <= len(convs) <= 20
                 and all(c.cin == 256 and c.cout == 256 and c.stride == 1 for c in convs))
 
     def _mid_blocks(self, plan, i, H, W, last) -> int:
@@ -364,7 +374,7 @@ class MuZeroNetwork:
         (mz_conv_chain_mid_bf16) serves: at most 4 (its 8 layers), never the network's last block (the
         kernel does not produce the spatial mean)."""
         n = 0
-        while (self.precision == "bf16" and H == 24 and W == 24 and n < 4 and i + n < len(plan) and i + n != last
+        while (self.op16 and H == 24 and W == 24 and n < 4 and i + n < len(plan) and i + n != last
                and plan[i + n][0] == "res"
                and all(c.cin == 128 and c.cout == 128 and c.stride == 1 for c in plan[i + n][1])):
             n += 1
@@ -390,7 +400,8 @@ class MuZeroNetwork:
                     arr[i] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), relu, res)
             cached = self._chains[key] = (arr, len(specs))
         arr, n = cached
-        _lib.call("mz_conv_chain_bf16x3" if self.split else "mz_conv_chain_bf16", _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
+        entry = "mz_conv_chain_bf16x3" if self.split else ("mz_conv_chain_f16" if self.half else "mz_conv_chain_bf16")
+        _lib.call(entry, _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
                   _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
                   _lib.ptr(mean_out), out.shape[0], _lib.current_stream())
 
@@ -443,10 +454,10 @@ class MuZeroNetwork:
                 cache = torch.empty(D, 9 * layer.cin * layer.cout, dtype=torch.float32, device=self.device)
             else:
                 from . import mfma
-                cache = torch.empty(D, mfma.packed_elems(layer.cout, layer.cin), dtype=torch.bfloat16,
-                                    device=self.device)
+                cache = torch.empty(D, mfma.packed_elems(layer.cout, layer.cin),
+                                    dtype=torch.float16 if self.half else torch.bfloat16, device=self.device)
             layer.dev["rot"] = cache
-            self._fold_pack(layer, 2 if self.precision == "fp32" else 0, cache, None, rot_depth=D)
+            self._fold_pack(layer, self._pack_mode, cache, None, rot_depth=D)
         return cache if newest is None else cache[newest]
 
     def represent(self, obs_nhwc: torch.Tensor, hidden_out: torch.Tensor, mean_out: torch.Tensor,
@@ -461,7 +472,7 @@ class MuZeroNetwork:
             B, H, W = obs_nhwc.shape[0], obs_nhwc.shape[1], obs_nhwc.shape[2] * 16
             _lib.expect(obs_nhwc, "observation", self.obs_dtype)
             first = self.rep_plan[0][1]
-            rot_kernel = (self.precision == "bf16" and (H, W, self.cin, first.cout) == (96, 96, 96, 256))
+            rot_kernel = (self.op16 and (H, W, self.cin, first.cout) == (96, 96, 96, 256))
             if not rot_kernel:     # validation precision / other shapes: undo the tiling, keep the permuted weights
                 from .prep import untile
                 obs_nhwc = untile(obs_nhwc).contiguous()
@@ -508,11 +519,12 @@ class MuZeroNetwork:
                     w = self._rotated_weights(item, None if on_device else rotation)
                 if i == 0 and rot_kernel and on_device:
                     _lib.expect(rotation, "rotation", torch.int32, (1,))
-                    _lib.call("mz_conv3x3_bf16_rot_sel", _lib.ptr(x), _lib.ptr(w), w.shape[1], _lib.ptr(rotation),
+                    _lib.call("mz_conv3x3_f16_rot_sel" if self.half else "mz_conv3x3_bf16_rot_sel", _lib.ptr(x), _lib.ptr(w),
+                              w.shape[1], _lib.ptr(rotation),
                               _lib.ptr(item.dev["bias"]), _lib.ptr(y), B, 1, _lib.current_stream())
                 elif i == 0 and rot_kernel:
-                    _lib.call("mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w), _lib.ptr(item.dev["bias"]), _lib.ptr(y),
-                              B, 1, _lib.current_stream())
+                    _lib.call("mz_conv3x3_f16_rot" if self.half else "mz_conv3x3_bf16_rot", _lib.ptr(x), _lib.ptr(w),
+                              _lib.ptr(item.dev["bias"]), _lib.ptr(y), B, 1, _lib.current_stream())
                 else:
                     self._conv(item, x, y, H, W, relu=True, mean_out=mean_out if final else None, weights=w)
                 x, H, W = y, HO, WO
@@ -530,8 +542,8 @@ class MuZeroNetwork:
                     for j, c in enumerate(convs):
                         arr[j] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), 1, j % 2)
                     cached = self._chains[key] = (arr, len(convs))
-                _lib.call("mz_conv_chain_mid_bf16", _lib.ptr(x), cached[0], cached[1], _lib.ptr(y), B,
-                          _lib.current_stream())
+                _lib.call("mz_conv_chain_mid_f16" if self.half else "mz_conv_chain_mid_bf16", _lib.ptr(x), cached[0],
+                          cached[1], _lib.ptr(y), B, _lib.current_stream())
                 x = y
             else:
                 c = item[0].cout

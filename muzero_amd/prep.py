@@ -37,8 +37,8 @@ class FrameRing:
         tile and slot: the last pixel of the tile to the left, the tile's 16 pixels, 5 values of padding; see
         mz_obs_slot_write): a push rewrites only the newest slot (3 values per pixel instead of the whole
         stack).  Call before ``reset``."""
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise ValueError("observation dtype must be bfloat16 or float32")
+        if dtype not in _OBS_FORMAT:
+            raise ValueError("observation dtype must be bfloat16, float16 or float32")
         if self.W % 16:
             raise ValueError("the rotating observation needs an image width that is a multiple of 16")
         self.rot = torch.zeros(self.B, self.H, self.W // 16, self.depth, ROT_RUN, dtype=dtype, device=self.device)
@@ -46,7 +46,7 @@ class FrameRing:
 
     def _write_rot(self, src: torch.Tensor, fill_all: int, mask: torch.Tensor = None) -> None:
         if self.rot is not None:
-            _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), 1 if self.rot.dtype == torch.bfloat16 else 0,
+            _lib.call("mz_obs_slot_write", _lib.ptr(src), _lib.ptr(self.rot), _OBS_FORMAT[self.rot.dtype],
                       self.B, self.depth, self.H, self.W, self.newest, fill_all, _lib.ptr(mask), _lib.current_stream())
             self.newest_dev.fill_(self.newest)
 
@@ -88,10 +88,10 @@ class FrameRing:
         value as (hi, lo) bf16 pairs [B, 2, H, W, 3*depth] (the bf16x3 precision's input)."""
         if pairs:
             dtype, shape, mode = torch.bfloat16, (self.B, 2, self.H, self.W, 3 * self.depth), 2
-        elif dtype in (torch.bfloat16, torch.float32):
-            shape, mode = (self.B, self.H, self.W, 3 * self.depth), 1 if dtype == torch.bfloat16 else 0
+        elif dtype in _OBS_FORMAT:
+            shape, mode = (self.B, self.H, self.W, 3 * self.depth), _OBS_FORMAT[dtype]
         else:
-            raise ValueError("observation dtype must be bfloat16 or float32")
+            raise ValueError("observation dtype must be bfloat16, float16 or float32")
         if out is None:
             out = torch.empty(*shape, dtype=dtype, device=self.device)
         _lib.expect(out, "out", dtype, shape)
@@ -100,6 +100,7 @@ class FrameRing:
         return out
 
 
+_OBS_FORMAT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 3}   # mz_ring_to_obs / mz_obs_slot_write codes
 ROT_RUN = 56     # values per (row, tile, slot) run of the rotating observation: 17 pixels x 3 + 5 of padding
 
 

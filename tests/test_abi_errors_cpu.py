@@ -53,6 +53,20 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_gather_stacked_obs", one, one, one, one, 0, 32, 9216, one, None)
     _fails("mz_comm_bcast_weights", None, one, 16, 0, None)
     _fails("mz_ring_to_obs", one, one, 5, 4, 32, 9216, 0, None, match="format")
+    # the IEEE-half entry points check as their bf16 namesakes do
+    _fails("mz_conv3x3_f16", None, None, 0, None, None, None, None, None, None, None, 1, 12, 12, 256, 256, 1, 1, None,
+           match="mz_conv3x3_f16: null tensor")
+    _fails("mz_conv3x3_f16", one, None, 0, one, one, None, one, None, None, None, 1, 10, 10, 64, 64, 1, 1, None,
+           match="no MFMA kernel")
+    _fails("mz_conv_chain_f16", one, None, 0, None, 5, one, None, None, None, 4, None, match="mz_conv_chain_f16: null")
+    _fails("mz_conv_chain_mid_f16", one, one, 9, one, 4, None, match="n_layers")
+    _fails("mz_conv3x3_f16_rot", None, one, one, one, 4, 1, None, match="null tensor")
+    _fails("mz_conv3x3_f16_rot_sel", one, one, 24, None, one, one, 4, 1, None, match="null index")
+    _fails("mz_conv3x3_f16_rot_sel", one, one, 12, one, one, one, 4, 1, None, match="16-byte aligned")
+    _fails("mz_obs_slot_write", one, C.c_void_p(32), 2, 4, 32, 96, 96, 0, 0, None, None, match="format")
+    _fails("mz_weights_fold_pack", one, None, None, None, None, None, 1e-5, 256, 256, 256, 4, 0, 0, one, None, None,
+           match="mode")
+    _fails("mz_pack_linear", one, None, 601, 256, 3, one, None, None, match="format")
 
 
 def test_size_queries():

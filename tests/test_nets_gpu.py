@@ -117,3 +117,67 @@ def test_layout_round_trip():
     z = torch.empty_like(x)
     _lib.call("mz_nhwc_to_nchw_f32", _lib.ptr(y), _lib.ptr(z), 3, 37, 35, _lib.current_stream())
     assert torch.equal(z, x)
+
+
+@pytest.mark.parametrize("A", [6, 18])
+def test_half_precision_network_against_reference_fixture(A):
+    """precision="f16" (IEEE-half operands at the bf16 matrix rate) against the reference's float32 outputs (g3):
+    every output the search consumes - policy, value and reward logits and the decoded scalars, through the
+    reference's call surface and through the rotating observation: logits within the float32-accurate
+    precisions' bound, |got - want| <= 2e-4 + 1e-3 |want|; the decoded scalars within twice that bound (the
+    inverse value transform amplifies a logit error, see the decode test of the oracle); hidden states (36 864
+    values that passed up to 25 layers of half-rounded activations) within 1 % of their RMS."""
+    from muzero_amd.network import MuZeroNetwork, support_to_scalar
+    from muzero_amd.prep import FrameRing, prepare_observation
+    from oracle import nets as onets
+    g = load("g3_nets_full")
+    torch.manual_seed(0)
+    ref = onets.Net(full_cfg(A)).eval()
+    onets.randomize_bn(ref, seed=1)
+    net = MuZeroNetwork(full_cfg(A), precision="f16", state_dict=ref.state_dict())
+    frames = np.random.default_rng(1234).integers(0, 256, size=(2, 96, 96, 96), dtype=np.uint8)
+    obs = prepare_observation(torch.from_numpy(frames))
+    act = torch.tensor([[1], [A - 1]])
+    o0 = net.initial_inference(obs)
+    o1 = net.recurrent_inference(o0.hidden_state, act)
+    o2 = net.recurrent_inference(o1.hidden_state, act.flip(0))
+    torch.cuda.synchronize()
+    report = {}
+
+    def chk(got, key, times=1.0):
+        want = g[f"A{A}_{key}"]
+        err = np.abs(got.cpu().numpy() - want) / (TOL["atol"] + TOL["rtol"] * np.abs(want))
+        report[key] = max(report.get(key, 0.0), round(float(err.max()), 3))
+        assert err.max() <= times, (key, float(err.max()))
+
+    def hidden(got, key):
+        want = g[f"A{A}_{key}"]
+        rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+        err = float(np.abs(got.cpu().numpy() - want).max()) / rms
+        report[key + " / RMS"] = round(err, 4)
+        assert err <= 0.01, (key, err)
+    hidden(o0.hidden_state[:1], "h0"); hidden(o1.hidden_state[:1], "h1")
+    chk(o0.policy_logits, "p0"); chk(o0.value, "v0")
+    chk(o1.policy_logits, "p1"); chk(o1.value, "v1"); chk(o1.reward, "r1")
+    chk(o2.policy_logits, "p2"); chk(o2.value, "v2"); chk(o2.reward, "r2")
+    chk(support_to_scalar(o0.value, 300), "sv0", 2.0); chk(support_to_scalar(o1.value, 300), "sv1", 2.0)
+    chk(support_to_scalar(o1.reward, 300), "sr1", 2.0)
+    # the same observation through the frame ring's rotating form, newest slot 7
+    junk = np.random.default_rng(77).integers(0, 256, size=(2, 96, 96, 3), dtype=np.uint8)
+    ring = FrameRing(2)
+    ring.enable_rotating(torch.float16)
+    ring.reset(torch.from_numpy(junk))
+    for _ in range(8):
+        ring.push(torch.from_numpy(junk))
+    for k in range(32):
+        ring.push(torch.from_numpy(np.ascontiguousarray(frames[..., 3 * k:3 * k + 3])))
+    rot, newest = ring.rotating_observation()
+    assert newest == 7 and rot.dtype == torch.float16
+    hid = torch.empty(2, 12, 12, 256, dtype=torch.float16, device="cuda")
+    mean = torch.empty(2, 256, dtype=torch.float32, device="cuda")
+    net.represent(rot, hid, mean, rotation=newest)
+    _, _, _, pl, vl, _ = net._heads(mean, 2, False, True)
+    chk(pl, "p0"); chk(vl, "v0"); chk(support_to_scalar(vl, 300), "sv0", 2.0)
+    hidden(hid[:1].permute(0, 3, 1, 2).float(), "h0")
+    print(f"f16 A={A}: worst error as a fraction of the 1e-3 bound (hidden states: of their RMS)", report)
+    assert torch.equal(ring.observation(torch.float16), obs.permute(0, 2, 3, 1).to(torch.float16))

@@ -80,18 +80,21 @@ def search_both(A, B, sims, precisions):
 # Two bf16 computations that differ only in the summation order of the first convolution are as far apart as
 # bf16 is from fp32: the statistic shows how a search amplifies last-bit differences at near-ties.
 # The bounds are ~1.5x the measured figures.
-@pytest.mark.parametrize("A,min_identical,min_same_top,max_tv,max_value", [(18, 0.88, 0.97, 0.013, 0.04),
-                                                                            (6, 0.60, 0.90, 0.027, 0.045)])
-def test_bf16_search_stays_close_to_fp32_search(A, min_identical, min_same_top, max_tv, max_value):
-    """Same weights, observations and noise searched in the validation precision (fp32) and in the
-    throughput precision (bf16): how far the visit distributions and root values move."""
+# f16 (IEEE-half operands, 8x smaller rounding steps): A=18: 100 %, 100 %, 0 %, 0.2 % (at 1024 games: 99.4 %, 99.9 %,
+# 0.10 %, 0.4 %); A=6: 92 %, 98 %, 0.7 %, 1.2 %
+@pytest.mark.parametrize("precision,A,min_identical,min_same_top,max_tv,max_value", [
+    ("bf16", 18, 0.88, 0.97, 0.013, 0.04), ("bf16", 6, 0.60, 0.90, 0.027, 0.045),
+    ("f16", 18, 0.97, 0.99, 0.002, 0.004), ("f16", 6, 0.85, 0.95, 0.011, 0.018)])
+def test_bf16_search_stays_close_to_fp32_search(precision, A, min_identical, min_same_top, max_tv, max_value):
+    """Same weights, observations and noise searched in the validation precision (fp32) and in a
+    throughput precision (bf16, f16): how far the visit distributions and root values move."""
     B, sims = 128, 50
-    res = search_both(A, B, sims, ("fp32", "bf16"))
-    (v32, q32), (v16, q16) = res["fp32"], res["bf16"]
+    res = search_both(A, B, sims, ("fp32", precision))
+    (v32, q32), (v16, q16) = res["fp32"], res[precision]
     tv = 0.5 * np.abs(v32 - v16).sum(1) / sims
     stats = dict(identical=float((v32 == v16).all(1).mean()), same_top=float((v32.argmax(1) == v16.argmax(1)).mean()),
                  tv=float(tv.mean()), value=float(np.abs(q32 - q16).mean() / np.abs(q32).mean()))
-    print("bf16 vs fp32 search", A, stats)
+    print(precision, "vs fp32 search", A, stats)
     assert stats["identical"] >= min_identical, stats
     assert stats["same_top"] >= min_same_top, stats
     assert stats["tv"] <= max_tv, stats

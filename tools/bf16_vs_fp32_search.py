@@ -2,7 +2,7 @@
 """How far the throughput precision moves the search result: the same observations, noise and
 weights searched with the fp32 validation path, with the bf16 path (stacked observation), with the bf16
 path on the rotating observation (what self-play runs: the first convolution sums in another order), and
-with the float32-accurate bf16x3 path; for each pair: agreement of the most-visited action, fraction of games
+with IEEE-half operands (f16) and with the float32-accurate bf16x3 path; for each pair: agreement of the most-visited action, fraction of games
 with identical visit counts, mean total-variation distance between visit distributions, root-value difference.
 usage: bf16_vs_fp32_search.py [B] [A] [sims] [seed]"""
 import json
@@ -34,7 +34,7 @@ for _ in range(31):
 noise = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=B)).cuda()
 res = {}
 for name, precision, rotating in (("fp32", "fp32", False), ("bf16", "bf16", False), ("bf16_rotating", "bf16", True),
-                                  ("bf16x3", "bf16x3", False)):
+                                  ("f16", "f16", False), ("bf16x3", "bf16x3", False)):
     net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
     m = BatchedMCTS(cfg, net, B, sims)
     if rotating:
@@ -58,4 +58,4 @@ def compare(a, b):
 
 print(json.dumps({"games": B, "actions": A, "sims": sims, "seed": seed,
                   "pairs": [compare("fp32", "bf16"), compare("fp32", "bf16_rotating"), compare("bf16", "bf16_rotating"),
-                            compare("fp32", "bf16x3")]}))
+                            compare("fp32", "f16"), compare("fp32", "bf16x3")]}))
