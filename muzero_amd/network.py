@@ -250,7 +250,10 @@ class MuZeroNetwork:
         self.dyn_first = ConvLayer(sd, "dynamics.conv_state", "dynamics.bn", 1)
         self.dyn_blocks = [self._res(sd, f"dynamics.resblocks.{j}") for j in range(cfg.num_blocks)]
         self.action_vec = torch.empty(self.A, self.W, dtype=torch.float32, device=self.device)     # [A][W]
-        hb = {"bf16": 1, "f16": 2}.get(self.precision, 0)  # heads follow the network's precision
+        # The heads of both 16-bit precisions run in IEEE half: their input is the float32 spatial mean, their FLOPs
+        # are negligible, and with bf16 weights and activations their own rounding - not the trunk's, which
+        # averages out in the mean - was three quarters of the bf16 precision's logit error
+        hb = 2 if self.op16 else 0
         self.policy = Head(sd, "prediction.policy_head", self.device, hb)
         self.value_head = Head(sd, "prediction.value_head", self.device, hb)
         self.reward_head = Head(sd, "dynamics.reward_head", self.device, hb)

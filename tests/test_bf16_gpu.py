@@ -23,9 +23,10 @@ def _nets(A, precision="bf16"):
 
 @pytest.mark.parametrize("A", [6, 18])
 def test_bf16_network_close_to_reference_fixture(A):
-    """bf16 activations and weights, fp32 accumulation, against the reference's float32 outputs (g3) at both
-    fixture action counts - 18 is the benchmark's.  The bound stated for this precision: the largest error of
-    an output tensor at most 2 % of that tensor's RMS (hidden states 6 %); the measured ratios are printed."""
+    """bf16 activations and weights in the convolutions (IEEE-half heads), fp32 accumulation, against the
+    reference's float32 outputs (g3) at both fixture action counts - 18 is the benchmark's.  The bound stated
+    for this precision: the largest error of a logit tensor at most 0.8 % of that tensor's RMS (measured
+    <= 0.5 %), decoded scalars 2 %, hidden states 6 % (measured 3-4 %); the measured ratios are printed."""
     from muzero_amd.network import support_to_scalar
     from muzero_amd.prep import prepare_observation
     g = load("g3_nets_full")
@@ -45,10 +46,10 @@ def test_bf16_network_close_to_reference_fixture(A):
         err = float(np.abs(got.cpu().numpy() - want).max())
         report[key] = round(err / max(rms, 1e-3), 4)
         assert err <= frac * max(rms, 1e-3), (key, err, rms)
-    close(o0.hidden_state[:1], "h0", 0.06); close(o0.policy_logits, "p0", 0.02); close(o0.value, "v0", 0.02)
-    close(o1.hidden_state[:1], "h1", 0.06); close(o1.policy_logits, "p1", 0.02)
-    close(o1.value, "v1", 0.02); close(o1.reward, "r1", 0.02)
-    close(o2.policy_logits, "p2", 0.02); close(o2.value, "v2", 0.02); close(o2.reward, "r2", 0.02)
+    close(o0.hidden_state[:1], "h0", 0.06); close(o0.policy_logits, "p0", 0.008); close(o0.value, "v0", 0.008)
+    close(o1.hidden_state[:1], "h1", 0.06); close(o1.policy_logits, "p1", 0.008)
+    close(o1.value, "v1", 0.008); close(o1.reward, "r1", 0.008)
+    close(o2.policy_logits, "p2", 0.008); close(o2.value, "v2", 0.008); close(o2.reward, "r2", 0.008)
     close(support_to_scalar(o0.value, 300), "sv0", 0.02); close(support_to_scalar(o1.value, 300), "sv1", 0.02)
     close(support_to_scalar(o1.reward, 300), "sr1", 0.02)
     print(f"bf16 vs reference fixture, A={A}: max error / RMS per output", report)
@@ -197,10 +198,10 @@ def test_full_size_search_properties_and_sampled_replay(A, B, precision):
 
 @pytest.mark.parametrize("B", [1, 15, 16, 333, 1024])
 def test_bf16_heads_match_their_arithmetic_in_torch(B):
-    """The heads on bf16 weights and bf16-rounded inputs with float32 accumulation, restated in torch (the spatial
-    means and the hidden layer rounded to bf16 exactly where the kernel rounds them).  Only the order of the
-    float32 partial sums differs - and with it, now and then, the bf16 rounding of a hidden unit that sits on a
-    rounding boundary (one flip moves a logit by ~3e-4): logits to 2e-3, priors to 1e-5 of the softmax of the
+    """The heads of the 16-bit precisions - IEEE-half weights and half-rounded inputs with float32 accumulation -
+    restated in torch (the spatial means and the hidden layer rounded to half exactly where the kernel rounds
+    them).  Only the order of the float32 partial sums differs - and with it, now and then, the rounding of a
+    hidden unit that sits on a rounding boundary: logits to 5e-4, priors to 1e-5 of the softmax of the
     kernel's own logits, decoded scalars to 1e-3 relative / 2e-3 absolute of the decode of the kernel's own logits
     (the decode itself is pinned bit for bit by the fixture test in test_nets_gpu.py).
     Batch sizes that leave the last workgroup's 16 samples partly or wholly empty included."""
@@ -210,7 +211,7 @@ def test_bf16_heads_match_their_arithmetic_in_torch(B):
     mean = (torch.randn(B, 256, device="cuda") * 0.5).contiguous()
     priors, value, reward, pl, vl, rl = net._heads(mean, B, True, True)
     torch.cuda.synchronize()
-    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    rb = lambda t: t.to(torch.float16).to(torch.float32)
 
     def mlp(seq, x):
         l1, l2 = seq[0], seq[2]
@@ -220,7 +221,7 @@ def test_bf16_heads_match_their_arithmetic_in_torch(B):
     for got, seq in ((pl, ref.prediction.policy_head), (vl, ref.prediction.value_head), (rl, ref.dynamics.reward_head)):
         want = mlp(seq, mean)
         rms = float(want.pow(2).mean().sqrt())
-        assert float((got - want).abs().max()) <= 2e-3 * max(rms, 1.0), (float((got - want).abs().max()), rms)
+        assert float((got - want).abs().max()) <= 5e-4 * max(rms, 1.0), (float((got - want).abs().max()), rms)
     assert float((priors - torch.softmax(pl, 1)).abs().max()) <= 1e-5
     for got, lg in ((value, vl), (reward, rl)):
         want = onets.decode_support(lg.cpu(), cfg.support_size).view(-1)

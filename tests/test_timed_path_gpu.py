@@ -91,7 +91,8 @@ def test_rotating_initial_inference_against_the_reference_fixture(A):
     logits, decoded value of model.py:332-338 in float32), reached through the timed path: the 32 frames of each
     observation pushed into the ring behind j frames of something else, so that the newest slot - and with it the
     weight copy the first convolution uses - takes every one of its 32 values; representation on the rotating
-    tensor, bf16 heads.  The bf16 bound stated for this precision: 2 % of the output's RMS (hidden state 6 %)."""
+    tensor, then the heads.  The bound stated for the bf16 precision: logits 0.8 % of the output's RMS, the
+    decoded value 2 %, the hidden state 6 %."""
     from muzero_amd.network import support_to_scalar
     from muzero_amd.prep import FrameRing
     g = load("g3_nets_full")
@@ -116,7 +117,7 @@ def test_rotating_initial_inference_against_the_reference_fixture(A):
         priors, value, _, pl, vl, _ = net._heads(mean, 2, False, True)
         torch.cuda.synchronize()
         got = {"h0": hidden[:1].permute(0, 3, 1, 2).float(), "p0": pl, "v0": vl, "sv0": support_to_scalar(vl, 300)}
-        for key, frac in (("h0", 0.06), ("p0", 0.02), ("v0", 0.02), ("sv0", 0.02)):
+        for key, frac in (("h0", 0.06), ("p0", 0.008), ("v0", 0.008), ("sv0", 0.02)):
             want = g[f"A{A}_{key}"]
             rms = max(float(np.sqrt((want.astype(np.float64) ** 2).mean())), 1e-3)
             err = float(np.abs(got[key].cpu().numpy() - want).max()) / rms

@@ -125,8 +125,10 @@ def test_full_size_update_native_against_torch_convolutions():
         if "head" in k:
             assert e_nat <= 0.05 * n + 1e-6, (k, e_nat, n)
         # (a convolution bias in front of a training-mode BatchNorm has a zero gradient in exact arithmetic:
-        # both sides hold rounding noise there, hence the floor relative to the whole gradient)
-        assert e_nat <= 1.15 * e_tor + 0.02 * n + 3e-4 * total, (k, e_nat, e_tor, n)
+        # both sides hold rounding noise there, hence the floor relative to the whole gradient; two runs of the SAME
+        # path differ too - MIOpen's kernels for the other layer shapes accumulate in no fixed order - and the ratio
+        # of the two noise norms has been seen between 0.8 and 1.27 for single parameters, hence the factor)
+        assert e_nat <= 1.35 * e_tor + 0.02 * n + 3e-4 * total, (k, e_nat, e_tor, n)
         worst = max(worst, e_nat / max(e_tor, 1e-12))
     print(f"native bf16 error / torch bf16 error against the float32 gradients, worst parameter: {worst:.3f}")
 

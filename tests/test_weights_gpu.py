@@ -19,23 +19,26 @@ def host_fold(sd, conv, bn):
 
 
 def host_linear(w, bf16):
+    """bf16: 0 float32 fragments, 1 bf16, 2 IEEE half (mz_pack_linear's format codes)."""
     O, K = w.shape
     tiles = (O + 15) // 16
     wp = torch.zeros(tiles * 16, K)
     wp[:O] = w.float()
     if bf16:
-        return wp.to(torch.bfloat16).view(tiles, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+        dt = torch.bfloat16 if bf16 == 1 else torch.float16
+        return wp.to(dt).view(tiles, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
     return wp.view(tiles, 16, K // 4, 4).permute(0, 2, 3, 1).contiguous().view(-1)
 
 
 def same_bits(a, b):
     a, b = a.detach().cpu().contiguous(), b.detach().cpu().contiguous()
     assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
-    return torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
-                       b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+    two = (torch.bfloat16, torch.float16)
+    return torch.equal(a.view(torch.int16 if a.dtype in two else torch.int32),
+                       b.view(torch.int16 if b.dtype in two else torch.int32))
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "bf16x3", "fp32"])
 def test_device_packed_weights_equal_host_packed(precision):
     from muzero_amd import mfma
     from muzero_amd.network import MuZeroNetwork, init_state_dict
@@ -44,6 +47,7 @@ def test_device_packed_weights_equal_host_packed(precision):
     sd = init_state_dict(cfg, seed=5, randomize_bn=True)
     net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
     first = net.rep_plan[0][1]
+    op_dtype = torch.float16 if precision == "f16" else torch.bfloat16
     if precision != "bf16x3":
         net._rotated_weights(first, 0)                      # builds the table of rotated copies
     for layer in net.all_convs():
@@ -52,7 +56,7 @@ def test_device_packed_weights_equal_host_packed(precision):
         if precision == "fp32":
             assert same_bits(layer.dev["w"], w.permute(2, 3, 1, 0).reshape(-1)), layer.name
         else:
-            assert same_bits(layer.dev["w"], mfma.pack_weights(w, layer.chunk)), layer.name
+            assert same_bits(layer.dev["w"], mfma.pack_weights(w, layer.chunk, op_dtype)), layer.name
             if precision == "bf16x3":
                 assert same_bits(layer.dev["w_lo"], mfma.pack_weights(w - w.to(torch.bfloat16).float(), layer.chunk))
     if precision != "bf16x3":
@@ -60,13 +64,13 @@ def test_device_packed_weights_equal_host_packed(precision):
         D = first.cin // 3
         for r in (0, 1, 17, D - 1):
             wr = w[:, rotation_permutation(D, r)]
-            want = wr.permute(2, 3, 1, 0).reshape(-1) if precision == "fp32" else mfma.pack_weights(wr, first.chunk)
+            want = wr.permute(2, 3, 1, 0).reshape(-1) if precision == "fp32" else mfma.pack_weights(wr, first.chunk, op_dtype)
             assert same_bits(first.dev["rot"][r], want), r
     wa = sd["dynamics.conv_action.weight"].float()[:, :, 0, 0]
     assert same_bits(net.action_vec, (wa.t() + sd["dynamics.conv_action.bias"].float()).contiguous())
     for head in (net.policy, net.value_head, net.reward_head):
         w1, w2 = sd[f"{head.name}.{head.k1}.weight"], sd[f"{head.name}.{head.k2}.weight"]
-        assert head.bf16 == (precision == "bf16")
+        assert head.bf16 == (2 if precision in ("bf16", "f16") else 0)      # both 16-bit precisions: IEEE-half heads
         assert same_bits(head.w1p, host_linear(w1, head.bf16)) and same_bits(head.w2p, host_linear(w2, head.bf16))
         assert same_bits(head.b1, sd[f"{head.name}.{head.k1}.bias"].float())
         b2 = torch.zeros((head.out + 15) // 16 * 16)
