@@ -239,6 +239,16 @@ __device__ __forceinline__ void stage_input_rot(char* lds, const T* src, int iy0
   }
 }
 
+// -DMZ_PATCH_STAMPS builds a diagnostic variant (tools/patch_phase_stamps.py): wavefront 0 of every 97th
+// workgroup records the shader clock at the phase boundaries of its patch (per channel chunk: start, window in
+// LDS, barrier passed, main loop done; then epilogue parked, barrier passed, stores issued).
+#ifdef MZ_PATCH_STAMPS
+__device__ long long g_patch_stamps[64 * 32];
+#define MZ_PSTAMP(i) if (pstamp) g_patch_stamps[pslot * 32 + (i)] = clock64()
+#else
+#define MZ_PSTAMP(i)
+#endif
+
 template <typename T, class C, bool ROT = false>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvArgs<T> a) {
   typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
@@ -248,6 +258,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / (C::PY * C::PX), patch = blockIdx.x % (C::PY * C::PX);
+#ifdef MZ_PATCH_STAMPS
+  const int pslot = (int)(blockIdx.x / 97) % 64;
+  const bool pstamp = blockIdx.x % 97 == 0 && blockIdx.x >= gridDim.x / 2 && tid == 0;   // second half: steady state
+#endif
   const int oy0 = (patch / C::PX) * C::TH, ox0 = (patch % C::PX) * C::TW;
   const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
   // elements per image: NHWC, or the rotating layout's runs of 56 values per (row, 16-pixel tile, slot)
@@ -306,9 +320,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
 
   for (int cc = 0; cc < C::NCC; ++cc) {
     if (cc > 0) __syncthreads();
+    MZ_PSTAMP(cc * 4 + 0);
     if constexpr (ROT) stage_input_rot<T, C>(lds, src, iy0, ix0, tid);
     else stage_input<T, C>(lds, src, av, cc, iy0, ix0, tid);
+    MZ_PSTAMP(cc * 4 + 1);
     __syncthreads();
+    MZ_PSTAMP(cc * 4 + 2);
     // software pipeline: a pixel tile's operand register is refilled with step st+1's operand
     // right after step st's MFMAs have read it
     bf16x8 af[MT];
@@ -334,6 +351,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    MZ_PSTAMP(cc * 4 + 3);
   }
 
   // epilogue, part 1: a lane holds channels cbase..cbase+3 of pixel (mt*16 + r16).  Bias,
@@ -366,7 +384,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
       }
     }
   }
+  MZ_PSTAMP(16);
   __syncthreads();
+  MZ_PSTAMP(17);
   // part 2: 16 bytes per lane, consecutive lanes on consecutive channels of a pixel
   constexpr int UPR = C::COUT / 8;  // 16-byte units per output pixel
   for (int u = tid; u < C::M * UPR; u += C::THREADS) {
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void conv3x3_bf16_kernel(ConvA
     const long o = (((long)b * C::HO + oy0 + py) * C::WO + ox0 + px) * C::COUT + c16 * 8;
     *reinterpret_cast<bf16x8*>(a.out + o) = *reinterpret_cast<const bf16x8*>(lds + m * OROW + c16 * 16);
   }
+  MZ_PSTAMP(18);
 }
 
 template <typename T, class C, bool ROT = false>
@@ -439,6 +460,12 @@ int check_chain_args(const char* what, const void* in, const mz_chain_layer* lay
 }
 
 }  // namespace
+
+#ifdef MZ_PATCH_STAMPS
+extern "C" int mz_debug_read_patch_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_patch_stamps), sizeof(long long) * 64 * 32);
+}
+#endif
 
 extern "C" {
 
