@@ -4,7 +4,7 @@
 # and of the training update; raw outputs under gpurun_out/prof_<tag>/, summaries written by
 # tools/summarize_profile.py.   usage: tools/profile_round.sh r02
 set -e
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
@@ -19,6 +19,9 @@ python3 tools/summarize_profile.py $out $tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/x3 -- python3 bench.py --steps 2 --warmup 1 --precision bf16x3 $B > $out/bench_x3.json 2> $out/x3.err
 python3 tools/top_kernels.py $out/x3 14 > $out/${tag}_x3_kernels.txt
 echo "x3 pass done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/f16 -- python3 bench.py --steps 2 --warmup 1 --precision f16 $B > $out/bench_f16.json 2> $out/f16.err
+python3 tools/top_kernels.py $out/f16 14 > $out/${tag}_f16_kernels.txt
+echo "f16 pass done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/train -- python3 tools/profile_train.py 128 bf16 native graphed > /dev/null 2> $out/train.err
 python3 tools/last_window.py $out/train 10.7 40 > $out/${tag}_train_update.txt
 echo "train pass done"
