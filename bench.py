@@ -185,18 +185,20 @@ def chain_roofline(wl, precision, traffic=None):
     flops = TRUNK_FLOPS * n_convs * wl.B
     achieved = flops / dur / 1e12
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    if precision == "bf16x3":
-        # three bf16 MFMAs per product: the matrix pipe executes 3x the algorithmic FLOPs, so the
-        # bound on ALGORITHMIC FLOP/s is a third of the dense bf16 peak
-        kernel, peak, executed = "conv_chain_x3_kernel", PEAK_BF16_TFLOPS / 3, 3 * achieved
+    if precision in ("bf16x3", "f16x2"):
+        # three bf16 (two half) MFMAs per product: the matrix pipe executes 3x (2x) the algorithmic FLOPs, so the
+        # bound on ALGORITHMIC FLOP/s is a third (half) of the dense 16-bit peak
+        per = 3 if precision == "bf16x3" else 2
+        kernel, peak, executed = "conv_chain_x3_kernel", PEAK_BF16_TFLOPS / per, per * achieved
     else:
         kernel, peak, executed = ("conv_chain_pair_kernel" if wl.B > n_cu else "conv_chain_kernel"), PEAK_BF16_TFLOPS, achieved
     out = {"bound": "mfma", "kernel": f"{kernel}: dynamics network, {n_convs} fused 3x3 convs 12x12x256->256",
            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
            "launch_us": dur * 1e6, "launches_timed": n_launches, "flops_per_launch": flops}
-    if precision == "bf16x3":
+    if precision in ("bf16x3", "f16x2"):
         out["executed_bf16_tflops"] = executed
-        out["peak_note"] = "2500 TFLOP/s dense bf16 / 3 MFMAs per product"
+        out["peak_note"] = ("2500 TFLOP/s dense bf16 / 3 MFMAs per product" if precision == "bf16x3" else
+                            "2500 TFLOP/s dense f16 / 2 MFMAs per product")
     return out, tree_s, heads_s
 
 
@@ -245,9 +247,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="games per GPU (default: the workload's)")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--wave", type=int, default=1)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16x3", "f16x2"],
                     help="bf16: throughput precision (the headline); f16: IEEE-half operands at the same matrix rate "
-                         "(outputs within 1e-3 of the reference's float32 path on its fixtures); bf16x3: float32-accurate")
+                         "(outputs within 1e-3 of the reference's float32 path on its fixtures); bf16x3 / f16x2: float32-accurate "
+                         "(three bf16 / two half MFMAs per product)")
     ap.add_argument("--graph", action="store_true", help="replay the search from a HIP graph")
     ap.add_argument("--from-host", action="store_true", help="include the pinned H2D copy of the new frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -324,7 +327,8 @@ def main():
             "metric": "mcts_sims_per_sec", "value": sims_per_s, "unit": "sims/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "f16": "f16"}.get(args.precision, "bf16x3 (float32-accurate: 3 bf16 MFMAs per product)"),
+            "dtype": {"bf16": "bf16", "f16": "f16", "f16x2": "f16x2 (float32-accurate: 2 half MFMAs per product)"}.get(
+                args.precision, "bf16x3 (float32-accurate: 3 bf16 MFMAs per product)"),
             "data": "synthetic",
             "config": {"workload": desc + f", wave {args.wave}", "games_per_gpu": B, "actions": A,
                        "sims_per_move": args.sims, "wave": args.wave, "parallelism": f"games sharded x{world}",
@@ -368,12 +372,13 @@ def main():
                 out["from_host"] = {"value": B * args.sims * n / t, "unit": "sims/s", "ms_per_step": t / n * 1e3,
                                     "h2d_bytes_per_step": B * 96 * 96 * 3}
             wl.free()
-            # (3) the other precisions on the same workload: the float32-accurate bf16x3 (meets the reference's fp32
-            # outputs to 1e-3 everywhere) and IEEE-half operands (same matrix rate as bf16, 8x smaller rounding steps)
+            # (3) the other precisions on the same workload: the float32-accurate bf16x3 and f16x2 (meet the reference's
+            # fp32 outputs to 1e-3 everywhere) and IEEE-half operands (same matrix rate as bf16, 8x smaller rounding steps)
             for key, other in (("secondary", "bf16x3" if args.precision != "bf16x3" else "bf16"),
+                               ("f16x2", "f16x2" if args.precision != "f16x2" else "bf16"),
                                ("f16", "f16" if args.precision != "f16" else "bf16")):
                 w2 = Workload(cfg, sd, device, B, args.sims, args.wave, other, rank)
-                t, n = w2.timed(max(2, args.steps // 2 if other != "bf16x3" else args.steps // 4), 1)
+                t, n = w2.timed(max(2, args.steps // 2 if other in ("bf16", "f16") else args.steps // 4), 1)
                 sec = {"precision": other, "value": B * args.sims * n / t, "unit": "sims/s", "ms_per_step": t / n * 1e3,
                        "steps": n, "config": out["config"]["workload"]}
                 sec["roofline"], _, _ = chain_roofline(w2, other)

@@ -277,6 +277,18 @@ int mz_conv_chain_bf16x3(const void* in, const int32_t* in_slot, int32_t slot_st
                          int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
                          float* mean_out, int32_t B, mz_stream_t stream);
 
+/* "f16x2": the float32-accurate path at two MFMAs per product - the same (hi, lo) pairs in IEEE half (22 significant
+ * bits together) with the weights rounded to half once: w * x = w_hi * x_hi + w_hi * x_lo.  Same contracts as the
+ * bf16x3 entry points above (model.py:332-348 to 1e-3), one weight array per layer (mz_weights_fold_pack mode 3;
+ * mz_chain_layer instead of mz_chain_layer_x3), tensors split by mz_split_f32_half. */
+int mz_split_f32_half(const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream);
+int mz_join_f32_half(const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream);
+int mz_conv3x3_f16x2(const void* in, const void* wpk, const float* bias, const void* residual, void* out, int32_t B,
+                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream);
+int mz_conv_chain_f16x2(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                        int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                        int32_t B, mz_stream_t stream);
+
 /* x.mean(dim=(2,3)) (model.py:243, :275): float NHWC [B][HW][C] -> [B][C]. */
 int mz_spatial_mean_f32(const float* in, float* out, int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
 
@@ -337,8 +349,9 @@ int mz_ring_push(uint8_t* ring, const uint8_t* frames, int32_t B, int32_t D, int
 
 /* Stacked, normalised observation from the ring: out[b][pixel][age*3 + rgb] =
  * frame(age)[pixel][rgb] / 255 with age 0 = oldest = slot (newest_slot+1) % D
- * (train.py:62-63 then :534-540). out is NHWC: float32 (out_is_bf16 = 0), bf16 (1), IEEE half (3), or the bf16x3
- * precision's (hi, lo) bf16 pairs of the float32 value, [B][2][HW][3*D] (2; needs 3*D % 8 == 0 and HW % 64 == 0). */
+ * (train.py:62-63 then :534-540). out is NHWC: float32 (out_is_bf16 = 0), bf16 (1), IEEE half (3), or the
+ * float32-accurate precisions' (hi, lo) pairs of the float32 value, [B][2][HW][3*D], in bf16 (2) or half (4); the
+ * pair formats need 3*D % 8 == 0 and HW % 64 == 0. */
 int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t B, int32_t D, int32_t HW,
                    int32_t newest_slot, mz_stream_t stream);
 

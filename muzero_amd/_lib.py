@@ -51,6 +51,10 @@ _SIGNATURES = {
     "mz_conv3x3_bf16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_conv_chain_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "mz_conv_chain_mid_bf16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),
+    "mz_conv3x3_f16x2": (C.c_int, [_P] * 5 + [C.c_int32] * 7 + [_P]),
+    "mz_conv_chain_f16x2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "mz_split_f32_half": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "mz_join_f32_half": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "mz_conv3x3_f16": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "mz_conv_chain_f16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "mz_conv_chain_mid_f16": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P]),

@@ -1,4 +1,4 @@
-// float32-accurate 3x3 convolutions on the bf16 matrix cores ("bf16x3"): every float32 value
+// float32-accurate 3x3 convolutions on the matrix cores.  "bf16x3": every float32 value
 // x travels as a pair of bf16 values (hi, lo) with hi = bf16(x), lo = bf16(x - hi), which
 // carries 16-17 significant bits, and a product w * x is formed as
 //     w_hi * x_hi + w_lo * x_hi + w_hi * x_lo
@@ -6,6 +6,12 @@
 // the rounding of the lo parts are ~2^-17 relative).  This is the precision in which the
 // networks meet the reference's float32 outputs to 1e-3 (model.py:332-348 on the torch CPU
 // path); the matrix pipe runs three times the bf16 kernels' work.
+//
+// "f16x2" (template arguments T = _Float16, WLO = false): the same pairs in IEEE half (hi carries 11 bits,
+// hi + lo 22) with the WEIGHTS rounded to half once, w * x = w_hi * x_hi + w_hi * x_lo - two MFMAs per product.
+// What is dropped is the weights' own rounding (2^-12 relative per weight, independent over the 2304 terms of a
+// sum) instead of a cross term; the activations, whose rounding would otherwise compound through 25 layers, stay
+// 22 bits wide.  Meets the same 1e-3 bound at 2/3 of the matrix work.
 //
 // A split tensor is stored component-major per image: [image][2 = hi, lo][pixels][channels].
 // Weights are two fragment arrays in the packing of mz_conv3x3_bf16 (hi and lo parts).
@@ -16,27 +22,29 @@
 
 namespace {
 
-__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, bf16x4& hi, bf16x4& lo) {
-  hi = bf16x4{(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
-  lo = bf16x4{(__bf16)(v0 - (float)hi[0]), (__bf16)(v1 - (float)hi[1]), (__bf16)(v2 - (float)hi[2]),
-              (__bf16)(v3 - (float)hi[3])};
+template <typename T>
+__device__ __forceinline__ void split4(float v0, float v1, float v2, float v3, vec4<T>& hi, vec4<T>& lo) {
+  hi = to_op4<T>(v0, v1, v2, v3);
+  lo = vec4<T>{(T)(v0 - (float)hi[0]), (T)(v1 - (float)hi[1]), (T)(v2 - (float)hi[2]), (T)(v3 - (float)hi[3])};
 }
 
 // ---------------------------------------------------------------------------
 // Patch kernel for the four non-trunk layer shapes (cf. conv3x3_bf16_kernel)
 // ---------------------------------------------------------------------------
+template <typename T>
 struct X3Args {
-  const __bf16* in;
-  const __bf16* wpk_hi;
-  const __bf16* wpk_lo;
+  const T* in;
+  const T* wpk_hi;
+  const T* wpk_lo;   // unused when the kernel forms two products
   const float* bias;
-  const __bf16* residual;
-  __bf16* out;
+  const T* residual;
+  T* out;
   int relu;
 };
 
-template <class C>
-__device__ __forceinline__ void stage_window(char* lds, const __bf16* src, int cc, int iy0, int ix0, int tid) {
+template <typename T, class C>
+__device__ __forceinline__ void stage_window(char* lds, const T* src, int cc, int iy0, int ix0, int tid) {
+  typedef vec8<T> bf16x8;   // eight operands of format T (the name predates the second format)
   constexpr int UPP = C::CINC / 8;
   constexpr int UNITS = C::IH * C::IW * UPP;
   constexpr int ROUNDS = (UNITS + C::THREADS - 1) / C::THREADS;
@@ -60,13 +68,16 @@ __device__ __forceinline__ void stage_window(char* lds, const __bf16* src, int c
       const int pix = u / UPP, cu = u % UPP;
       const int iy = iy0 + pix / C::IW, ix = ix0 + pix % C::IW;
       const bool inside = iy >= 0 && iy < C::HIN && ix >= 0 && ix < C::WIN;
-      *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = inside ? v[i] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<bf16x8*>(lds + pix * C::ROWB + cu * 16) = inside ? v[i] : zero8<T>();
     }
   }
 }
 
-template <class C>
-__global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
+// WLO: form w_lo * x_hi too (three products); without it the weights are hi only (two products)
+template <typename T, bool WLO, class C>
+__global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int MT = C::MT, WN = C::WN, KC = C::KC;
   constexpr int WIN_B = C::LDS_BYTES;  // one component's window; the lo window follows the hi window
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
   const int b = blockIdx.x / (C::PY * C::PX), patch = blockIdx.x % (C::PY * C::PX);
   const int oy0 = (patch / C::PX) * C::TH, ox0 = (patch % C::PX) * C::TW;
   constexpr long IMG_IN = (long)C::HIN * C::WIN * C::CIN, IMG_OUT = (long)C::HO * C::WO * C::COUT;
-  const __bf16* src = a.in + (long)b * 2 * IMG_IN;
+  const T* src = a.in + (long)b * 2 * IMG_IN;
   const int iy0 = oy0 * C::S - 1, ix0 = ox0 * C::S - 1;
   const int r16 = lane & 15, kq = lane >> 4;
 
@@ -86,9 +97,9 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
     for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   constexpr int WSTEP = C::NTILES * 1024;
-  const __amdgpu_buffer_rsrc_t wrh = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk_hi), 0,
+  const __amdgpu_buffer_rsrc_t wrh = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.wpk_hi), 0,
                                                                        (C::KSTEPS + 2) * WSTEP, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrl = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wpk_lo), 0,
+  const __amdgpu_buffer_rsrc_t wrl = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(WLO ? a.wpk_lo : a.wpk_hi), 0,
                                                                        (C::KSTEPS + 2) * WSTEP, 0x00020000);
   const int wlane = wave * (WN * 1024) + lane * 16;
   auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     wh[nt] = wfrag(wrh, 0, nt);
-    wl[nt] = wfrag(wrl, 0, nt);
+    if constexpr (WLO) wl[nt] = wfrag(wrl, 0, nt);
   }
   int wp = WSTEP;
 
@@ -120,8 +131,8 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
 
   for (int cc = 0; cc < C::NCC; ++cc) {
     if (cc > 0) __syncthreads();
-    stage_window<C>(lds, src, cc, iy0, ix0, tid);
-    stage_window<C>(lds + WIN_B, src + IMG_IN, cc, iy0, ix0, tid);
+    stage_window<T, C>(lds, src, cc, iy0, ix0, tid);
+    stage_window<T, C>(lds + WIN_B, src + IMG_IN, cc, iy0, ix0, tid);
     __syncthreads();
     bf16x8 af[MT];
 #pragma unroll
@@ -132,32 +143,31 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) {
         w2h[nt] = wfrag(wrh, wp, nt);
-        w2l[nt] = wfrag(wrl, wp, nt);
+        if constexpr (WLO) w2l[nt] = wfrag(wrl, wp, nt);
       }
       wp += WSTEP;
-      // w_hi * x_hi, then w_lo * x_hi (after which the operand register takes x_lo), then w_hi * x_lo
-      // (after which it takes the next step's x_hi)
+      // w_hi * x_hi, then (three products) w_lo * x_hi, after which the operand register takes x_lo, then
+      // w_hi * x_lo, after which it takes the next step's x_hi
+      if constexpr (WLO) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(wh[nt], af[mt], acc[mt][nt]);
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(WLO ? wl[nt] : wh[nt], af[mt], acc[mt][nt]);
         af[mt] = *(lds_frag_ptr)(abase[mt] + (WIN_B + step_offset(st)));
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(wh[nt], af[mt], acc[mt][nt]);
         if (st + 1 < NS) af[mt] = *(lds_frag_ptr)(abase[mt] + step_offset(st + 1));
       }
-      __builtin_amdgcn_sched_group_barrier(0x020, 2 * WN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, MT * WN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, (WLO ? 2 : 1) * WN, 0);
+      if constexpr (WLO) __builtin_amdgcn_sched_group_barrier(0x008, MT * WN, 0);
 #pragma unroll
       for (int i = 0; i < 2 * MT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
 #pragma unroll
       for (int nt = 0; nt < WN; ++nt) {
         wh[nt] = w2h[nt];
-        wl[nt] = w2l[nt];
+        if constexpr (WLO) wl[nt] = w2l[nt];
       }
     }
   }
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
   constexpr int TILE_B = C::M * OROW;
   static_assert(2 * TILE_B <= 2 * C::LDS_BYTES, "output tiles must fit in the input windows' LDS");
   __syncthreads();
-  const __bf16* res = a.residual ? a.residual + (long)b * 2 * IMG_OUT : nullptr;
+  const T* res = a.residual ? a.residual + (long)b * 2 * IMG_OUT : nullptr;
 #pragma unroll
   for (int nt = 0; nt < WN; ++nt) {
     const int cbase = (wave * WN + nt) * 16 + kq * 4;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
         bf16x4 hi, lo;
-        split4(v0, v1, v2, v3, hi, lo);
+        split4<T>(v0, v1, v2, v3, hi, lo);
         *reinterpret_cast<bf16x4*>(lds + m * OROW + cbase * 2) = hi;
         *reinterpret_cast<bf16x4*>(lds + TILE_B + m * OROW + cbase * 2) = lo;
       }
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
   }
   __syncthreads();
   constexpr int UPR = C::COUT / 8;
-  __bf16* dst = a.out + (long)b * 2 * IMG_OUT;
+  T* dst = a.out + (long)b * 2 * IMG_OUT;
   for (int u = tid; u < 2 * C::M * UPR; u += C::THREADS) {
     const int comp = u / (C::M * UPR), r = u % (C::M * UPR);
     const int m = r / UPR, c16 = r % UPR;
@@ -219,15 +229,15 @@ __global__ __launch_bounds__(C::THREADS, 1) void conv3x3_x3_kernel(X3Args a) {
   }
 }
 
-template <class C>
-int launch_x3(const X3Args& a, int B, hipStream_t stream) {
+template <typename T, bool WLO, class C>
+int launch_x3(const X3Args<T>& a, int B, hipStream_t stream) {
   static bool configured[mz::kMaxDevices] = {false};
-  auto kern = conv3x3_x3_kernel<C>;
+  auto kern = conv3x3_x3_kernel<T, WLO, C>;
   constexpr int lds = 2 * C::LDS_BYTES;
   static_assert(lds <= 160 * 1024, "two input windows must fit in a CU's LDS");
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv3x3_x3")) return rc;
   hipLaunchKernelGGL(kern, dim3(B * C::PY * C::PX), dim3(C::THREADS), lds, stream, a);
-  return mz::check_launch("mz_conv3x3_bf16x3");
+  return mz::check_launch(WLO ? "mz_conv3x3_bf16x3" : "mz_conv3x3_f16x2");
 }
 
 template <class C>
@@ -239,24 +249,28 @@ bool matches(int H, int W, int Cin, int Cout, int stride) {
 // Chain of 12x12 256->256 layers with one game's (hi, lo) pair resident in LDS
 // (cf. conv_chain_pair_kernel: the lo component sits where that kernel keeps its second image)
 // ---------------------------------------------------------------------------
+template <typename T>
 struct ChainX3Args {
-  const __bf16* in;
+  const T* in;
   const int* in_slot;
   int slot_stride;
-  __bf16* out;
+  T* out;
   const float* avec;
   const int* actions;
   float* mean_out;
   int B;
   int n_layers;
-  const __bf16* wpk_hi[kMaxChain];
-  const __bf16* wpk_lo[kMaxChain];
+  const T* wpk_hi[kMaxChain];
+  const T* wpk_lo[kMaxChain];   // unused when the kernel forms two products
   const float* bias[kMaxChain];
   unsigned relu_mask;
   unsigned res_mask;
 };
 
-__global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
+template <typename T, bool WLO>
+__global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args<T> a) {
+  typedef vec8<T> bf16x8;   // eight / four operands of format T (the names predate the second format)
+  typedef vec4<T> bf16x4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NW = 8, WN = 2;
   constexpr int WSTEP = 16 * 1024;
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
   auto plane_of = [](int q) { return (q & 3) * 8 + (q >> 2); };
 
   {  // zero pixels of all 64 planes (never written afterwards)
-    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 z = zero8<T>();
     for (int s = tid; s < 2 * kPlanes * 16; s += NW * 64)
       *reinterpret_cast<bf16x8*>(lds + (s >> 4) * kPlaneB + (kPix + (s & 15)) * 16) = z;
   }
@@ -295,22 +309,22 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
   auto wfrag = [&](__amdgpu_buffer_rsrc_t r, int step_off, int nt) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, wlane + nt * 1024, step_off, 0));
   };
-  auto wdesc = [&](const __bf16* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
+  auto wdesc = [&](const T* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), 0, (9 * kKC + 2) * WSTEP, 0x00020000);
   };
   const int pl = lane & 15, qq = lane >> 4;
 
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const long img = a.in_slot ? (long)a.in_slot[b] * a.slot_stride + b : b;
-    const __bf16* src = a.in + img * 2 * IMG;
+    const T* src = a.in + img * 2 * IMG;
     const float* av = a.avec ? a.avec + (long)a.actions[b] * kCh : nullptr;
 
-    __amdgpu_buffer_rsrc_t wrh = wdesc(a.wpk_hi[0]), wrl = wdesc(a.wpk_lo[0]);
+    __amdgpu_buffer_rsrc_t wrh = wdesc(a.wpk_hi[0]), wrl = wdesc(WLO ? a.wpk_lo[0] : a.wpk_hi[0]);
     bf16x8 wh[WN], wl[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
       wh[nt] = wfrag(wrh, 0, nt);
-      wl[nt] = wfrag(wrl, 0, nt);
+      if constexpr (WLO) wl[nt] = wfrag(wrl, 0, nt);
     }
     int wp = WSTEP;
 
@@ -334,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float v = ((float)vh[j][e] + (float)vl[j][e]) + add[e];
-            vh[j][e] = (__bf16)v;
-            vl[j][e] = (__bf16)(v - (float)vh[j][e]);
+            vh[j][e] = to_op<T>(v);
+            vl[j][e] = (T)(v - (float)vh[j][e]);
           }
         }
       }
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
     for (int l = 0; l < a.n_layers; ++l) {
       const bool last = l == a.n_layers - 1;
       const int ln = last ? l : l + 1;
-      const __amdgpu_buffer_rsrc_t wrh_next = wdesc(a.wpk_hi[ln]), wrl_next = wdesc(a.wpk_lo[ln]);
+      const __amdgpu_buffer_rsrc_t wrh_next = wdesc(a.wpk_hi[ln]), wrl_next = wdesc(WLO ? a.wpk_lo[ln] : a.wpk_hi[ln]);
 
       int aaddr[kMT];
       tap_addresses(0, aaddr);
@@ -375,25 +389,26 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {
             w2h[nt] = wfrag(wrh, wp, nt);
-            w2l[nt] = wfrag(wrl, wp, nt);
+            if constexpr (WLO) w2l[nt] = wfrag(wrl, wp, nt);
           }
           wp += WSTEP;
           // w_hi * x_hi
+          if constexpr (WLO) {
 #pragma unroll
-          for (int mt = 0; mt < kMT; ++mt)
+            for (int mt = 0; mt < kMT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
-          // w_lo * x_hi; each operand register is then refilled with x_lo of this k-step
+              for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(wh[nt], af[mt], acc[mt][nt]);
+          }
+          // w_lo * x_hi (three products) or w_hi * x_hi (two); each operand register is then refilled with x_lo
+          // of this k-step
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(WLO ? wl[nt] : wh[nt], af[mt], acc[mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kPlaneB + kc * KOFF));
           }
-          __builtin_amdgcn_sched_group_barrier(0x020, 2 * WN, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, kMT * WN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, (WLO ? 2 : 1) * WN, 0);
+          if constexpr (WLO) __builtin_amdgcn_sched_group_barrier(0x008, kMT * WN, 0);
 #pragma unroll
           for (int i = 0; i < kMT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, WN, 0);
@@ -405,8 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt) {
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = mfma_16x16x32(wh[nt], af[mt], acc[mt][nt]);
             af[mt] = *(lds_frag_ptr)(aaddr[mt] + (kc < kKC - 1 ? (kc + 1) * KOFF : 0));
           }
 #pragma unroll
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
           for (int nt = 0; nt < WN; ++nt) {
             wh[nt] = w2h[nt];
-            wl[nt] = w2l[nt];
+            if constexpr (WLO) wl[nt] = w2l[nt];
           }
         }
       }
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
           wh[nt] = wfrag(wrh, 0, nt);
-          wl[nt] = wfrag(wrl, 0, nt);
+          if constexpr (WLO) wl[nt] = wfrag(wrl, 0, nt);
         }
         wp = WSTEP;
 #pragma unroll
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
           }
           s0 += v0; s1 += v1; s2 += v2; s3 += v3;
           bf16x4 hi, lo;
-          split4(v0, v1, v2, v3, hi, lo);
+          split4<T>(v0, v1, v2, v3, hi, lo);
           *reinterpret_cast<bf16x4*>(slot) = hi;
           *reinterpret_cast<bf16x4*>(slot + kPlaneB) = lo;
         }
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
       __syncthreads();
     }
 
-    __bf16* dst = a.out + (long)b * 2 * IMG;
+    T* dst = a.out + (long)b * 2 * IMG;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -498,20 +512,97 @@ __global__ __launch_bounds__(512, 2) void conv_chain_x3_kernel(ChainX3Args a) {
 }
 
 // float32 [n] <-> split bf16 pairs laid out [n / per_image][2][per_image]
-__global__ void split_kernel(const float* __restrict__ x, __bf16* __restrict__ out, long n, long per_image) {
+template <typename T>
+__global__ void split_kernel(const float* __restrict__ x, T* __restrict__ out, long n, long per_image) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long img = i / per_image, r = i - img * per_image;
   const float v = x[i];
-  const __bf16 hi = (__bf16)v;
+  const T hi = to_op<T>(v);
   out[img * 2 * per_image + r] = hi;
-  out[img * 2 * per_image + per_image + r] = (__bf16)(v - (float)hi);
+  out[img * 2 * per_image + per_image + r] = (T)(v - (float)hi);
 }
-__global__ void join_kernel(const __bf16* __restrict__ x, float* __restrict__ out, long n, long per_image) {
+template <typename T>
+__global__ void join_kernel(const T* __restrict__ x, float* __restrict__ out, long n, long per_image) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const long img = i / per_image, r = i - img * per_image;
   out[i] = (float)x[img * 2 * per_image + r] + (float)x[img * 2 * per_image + per_image + r];
+}
+
+template <typename T, bool WLO>
+int conv3x3_split_any(const char* what, const void* in, const void* wpk_hi, const void* wpk_lo, const float* bias,
+                      const void* residual, void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                      int32_t stride, int32_t relu, mz_stream_t stream) {
+  MZ_REQUIRE(in && wpk_hi && (wpk_lo || !WLO) && bias && out && B > 0, "%s: null tensor or empty batch", what);
+  X3Args<T> a{static_cast<const T*>(in), static_cast<const T*>(wpk_hi), static_cast<const T*>(wpk_lo), bias,
+              static_cast<const T*>(residual), static_cast<T*>(out), relu};
+  hipStream_t s = mz::as_stream(stream);
+  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch_x3<T, WLO, ConvStem>(a, B, s);
+  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch_x3<T, WLO, ConvDown0>(a, B, s);
+  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch_x3<T, WLO, ConvMid>(a, B, s);
+  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch_x3<T, WLO, ConvDown1>(a, B, s);
+  return mz::fail(MZ_E_ARG, "%s: no kernel for %dx%d, %d->%d channels, stride %d (the 12x12 256->256 layers go "
+                  "through the chain entry point)", what, H, W, Cin, Cout, stride);
+}
+
+// layers: mz_chain_layer_x3 (WLO) or mz_chain_layer (two products: one weight array per layer)
+template <typename T, bool WLO, typename Layer>
+int conv_chain_split_any(const char* what, const void* in, const int32_t* in_slot, int32_t slot_stride, const Layer* layers,
+                         int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                         int32_t B, mz_stream_t stream) {
+  MZ_REQUIRE(in && layers && out && B > 0, "%s: null tensor or empty batch", what);
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= kMaxChain, "%s: n_layers must be 1..20 (got %d)", what, n_layers);
+  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "%s: action_vec and actions go together", what);
+  MZ_REQUIRE(!layers[0].add_residual, "%s: the first layer has no residual source", what);
+  ChainX3Args<T> a{};
+  a.in = static_cast<const T*>(in);
+  a.in_slot = in_slot;
+  a.slot_stride = slot_stride;
+  a.out = static_cast<T*>(out);
+  a.avec = action_vec;
+  a.actions = actions;
+  a.mean_out = mean_out;
+  a.B = B;
+  a.n_layers = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    if constexpr (WLO) {
+      MZ_REQUIRE(layers[l].wpk_hi && layers[l].wpk_lo && layers[l].bias, "%s: layer %d is null", what, l);
+      a.wpk_hi[l] = static_cast<const T*>(layers[l].wpk_hi);
+      a.wpk_lo[l] = static_cast<const T*>(layers[l].wpk_lo);
+    } else {
+      MZ_REQUIRE(layers[l].wpk && layers[l].bias, "%s: layer %d is null", what, l);
+      a.wpk_hi[l] = static_cast<const T*>(layers[l].wpk);
+    }
+    a.bias[l] = layers[l].bias;
+    if (layers[l].relu) a.relu_mask |= 1u << l;
+    if (layers[l].add_residual) a.res_mask |= 1u << l;
+  }
+  constexpr int lds = 2 * kLdsBytes;
+  static bool configured[mz::kMaxDevices] = {false};
+  auto kern = conv_chain_x3_kernel<T, WLO>;
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured, "conv_chain_x3")) return rc;
+  const int n_cu = mz::compute_units();
+  hipLaunchKernelGGL(kern, dim3(B < n_cu ? B : n_cu), dim3(512), lds, mz::as_stream(stream), a);
+  return mz::check_launch(what);
+}
+
+template <typename T>
+int split_any(const char* what, const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "%s: bad arguments", what);
+  const long n = n_images * per_image;
+  hipLaunchKernelGGL(split_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream), x,
+                     static_cast<T*>(out), n, (long)per_image);
+  return mz::check_launch(what);
+}
+
+template <typename T>
+int join_any(const char* what, const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "%s: bad arguments", what);
+  const long n = n_images * per_image;
+  hipLaunchKernelGGL(join_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream),
+                     static_cast<const T*>(x), out, n, (long)per_image);
+  return mz::check_launch(what);
 }
 
 }  // namespace
@@ -521,67 +612,41 @@ extern "C" {
 int mz_conv3x3_bf16x3(const void* in, const void* wpk_hi, const void* wpk_lo, const float* bias, const void* residual,
                       void* out, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride,
                       int32_t relu, mz_stream_t stream) {
-  MZ_REQUIRE(in && wpk_hi && wpk_lo && bias && out && B > 0, "mz_conv3x3_bf16x3: null tensor or empty batch");
-  X3Args a{static_cast<const __bf16*>(in), static_cast<const __bf16*>(wpk_hi), static_cast<const __bf16*>(wpk_lo),
-           bias, static_cast<const __bf16*>(residual), static_cast<__bf16*>(out), relu};
-  hipStream_t s = mz::as_stream(stream);
-  if (matches<ConvStem>(H, W, Cin, Cout, stride)) return launch_x3<ConvStem>(a, B, s);
-  if (matches<ConvDown0>(H, W, Cin, Cout, stride)) return launch_x3<ConvDown0>(a, B, s);
-  if (matches<ConvMid>(H, W, Cin, Cout, stride)) return launch_x3<ConvMid>(a, B, s);
-  if (matches<ConvDown1>(H, W, Cin, Cout, stride)) return launch_x3<ConvDown1>(a, B, s);
-  return mz::fail(MZ_E_ARG, "mz_conv3x3_bf16x3: no kernel for %dx%d, %d->%d channels, stride %d (the 12x12 "
-                  "256->256 layers go through mz_conv_chain_bf16x3)", H, W, Cin, Cout, stride);
+  return conv3x3_split_any<__bf16, true>("mz_conv3x3_bf16x3", in, wpk_hi, wpk_lo, bias, residual, out, B, H, W, Cin, Cout,
+                                         stride, relu, stream);
+}
+
+int mz_conv3x3_f16x2(const void* in, const void* wpk, const float* bias, const void* residual, void* out, int32_t B,
+                     int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t stride, int32_t relu, mz_stream_t stream) {
+  return conv3x3_split_any<_Float16, false>("mz_conv3x3_f16x2", in, wpk, nullptr, bias, residual, out, B, H, W, Cin, Cout,
+                                            stride, relu, stream);
 }
 
 int mz_conv_chain_bf16x3(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer_x3* layers,
                          int32_t n_layers, void* out, const float* action_vec, const int32_t* actions,
                          float* mean_out, int32_t B, mz_stream_t stream) {
-  MZ_REQUIRE(in && layers && out && B > 0, "mz_conv_chain_bf16x3: null tensor or empty batch");
-  MZ_REQUIRE(n_layers >= 1 && n_layers <= kMaxChain, "mz_conv_chain_bf16x3: n_layers must be 1..20 (got %d)", n_layers);
-  MZ_REQUIRE((action_vec == nullptr) == (actions == nullptr), "mz_conv_chain_bf16x3: action_vec and actions go together");
-  MZ_REQUIRE(!layers[0].add_residual, "mz_conv_chain_bf16x3: the first layer has no residual source");
-  ChainX3Args a{};
-  a.in = static_cast<const __bf16*>(in);
-  a.in_slot = in_slot;
-  a.slot_stride = slot_stride;
-  a.out = static_cast<__bf16*>(out);
-  a.avec = action_vec;
-  a.actions = actions;
-  a.mean_out = mean_out;
-  a.B = B;
-  a.n_layers = n_layers;
-  for (int l = 0; l < n_layers; ++l) {
-    MZ_REQUIRE(layers[l].wpk_hi && layers[l].wpk_lo && layers[l].bias, "mz_conv_chain_bf16x3: layer %d is null", l);
-    a.wpk_hi[l] = static_cast<const __bf16*>(layers[l].wpk_hi);
-    a.wpk_lo[l] = static_cast<const __bf16*>(layers[l].wpk_lo);
-    a.bias[l] = layers[l].bias;
-    if (layers[l].relu) a.relu_mask |= 1u << l;
-    if (layers[l].add_residual) a.res_mask |= 1u << l;
-  }
-  constexpr int lds = 2 * kLdsBytes;
-  static bool configured[mz::kMaxDevices] = {false};
-  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_chain_x3_kernel), lds, configured,
-                                      "conv_chain_x3"))
-    return rc;
-  const int n_cu = mz::compute_units();
-  hipLaunchKernelGGL(conv_chain_x3_kernel, dim3(B < n_cu ? B : n_cu), dim3(512), lds, mz::as_stream(stream), a);
-  return mz::check_launch("mz_conv_chain_bf16x3");
+  return conv_chain_split_any<__bf16, true>("mz_conv_chain_bf16x3", in, in_slot, slot_stride, layers, n_layers, out,
+                                            action_vec, actions, mean_out, B, stream);
+}
+
+int mz_conv_chain_f16x2(const void* in, const int32_t* in_slot, int32_t slot_stride, const mz_chain_layer* layers,
+                        int32_t n_layers, void* out, const float* action_vec, const int32_t* actions, float* mean_out,
+                        int32_t B, mz_stream_t stream) {
+  return conv_chain_split_any<_Float16, false>("mz_conv_chain_f16x2", in, in_slot, slot_stride, layers, n_layers, out,
+                                               action_vec, actions, mean_out, B, stream);
 }
 
 int mz_split_f32(const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
-  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "mz_split_f32: bad arguments");
-  const long n = n_images * per_image;
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream), x,
-                     static_cast<__bf16*>(out), n, (long)per_image);
-  return mz::check_launch("mz_split_f32");
+  return split_any<__bf16>("mz_split_f32", x, out, n_images, per_image, stream);
 }
-
 int mz_join_f32(const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
-  MZ_REQUIRE(x && out && n_images > 0 && per_image > 0, "mz_join_f32: bad arguments");
-  const long n = n_images * per_image;
-  hipLaunchKernelGGL(join_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mz::as_stream(stream),
-                     static_cast<const __bf16*>(x), out, n, (long)per_image);
-  return mz::check_launch("mz_join_f32");
+  return join_any<__bf16>("mz_join_f32", x, out, n_images, per_image, stream);
+}
+int mz_split_f32_half(const float* x, void* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  return split_any<_Float16>("mz_split_f32_half", x, out, n_images, per_image, stream);
+}
+int mz_join_f32_half(const void* x, float* out, int64_t n_images, int64_t per_image, mz_stream_t stream) {
+  return join_any<_Float16>("mz_join_f32_half", x, out, n_images, per_image, stream);
 }
 
 }  // extern "C"

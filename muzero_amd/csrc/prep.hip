@@ -16,6 +16,11 @@ __device__ __forceinline__ unsigned short f32_to_16(float f) {
   if constexpr (HALF) return __builtin_bit_cast(unsigned short, (_Float16)f);
   else return f32_to_bf16_rne(f);
 }
+template <bool HALF>
+__device__ __forceinline__ float f32_from_16(unsigned short h) {
+  if constexpr (HALF) return (float)__builtin_bit_cast(_Float16, h);
+  else return __uint_as_float((unsigned)h << 16);
+}
 
 // ring [B][D][frame_bytes]; frames [B][frame_bytes].  fill_all != 0 copies the
 // frame into every slot (the reset rule, train.py:49-50).
@@ -68,8 +73,8 @@ __global__ __launch_bounds__(256) void ring_to_obs_kernel(const unsigned char* _
 // Fast path of the same conversion for 3*D a multiple of 8 and HW a multiple of 64: every
 // global access is 16 bytes per lane (the byte-at-a-time version above is bound by the
 // number of memory instructions, not by bytes).
-// SPLIT: OutT is bf16 and the output is the (hi, lo) pair layout [B][2][HW][C] of the bf16x3 precision:
-// hi = bf16(v), lo = bf16(v - hi).
+// SPLIT: OutT is 16-bit and the output is the (hi, lo) pair layout [B][2][HW][C] of the float32-accurate
+// precisions: hi = round16(v), lo = round16(v - hi), in bf16 or (HALF) IEEE half.
 template <typename OutT, bool SPLIT = false, bool HALF = false>
 __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned char* __restrict__ ring,
                                                              OutT* __restrict__ out, int D, int HW, int newest) {
@@ -98,8 +103,10 @@ __global__ __launch_bounds__(256) void ring_to_obs_vec_kernel(const unsigned cha
       unsigned short hi[8], lo[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        hi[j] = f32_to_bf16_rne(v[j]);
-        lo[j] = f32_to_bf16_rne(v[j] - __uint_as_float((unsigned)hi[j] << 16));
+        hi[j] = f32_to_16<HALF>(v[j]);
+        const float rest = v[j] - f32_from_16<HALF>(hi[j]);      // may be negative: the generic conversion
+        if constexpr (HALF) lo[j] = __builtin_bit_cast(unsigned short, (_Float16)rest);
+        else lo[j] = __builtin_bit_cast(unsigned short, (__bf16)rest);
       }
       const long oh = ((long)b * 2 * HW + p0 + px) * C + c0, ol = oh + (long)HW * C;
       *reinterpret_cast<uint4*>(out + oh) = make_uint4(hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16),
@@ -237,8 +244,14 @@ int mz_ring_to_obs(const uint8_t* ring, void* out, int32_t out_is_bf16, int32_t 
   const size_t lds = (size_t)D * kPix * 3;
   MZ_REQUIRE(lds <= 64 * 1024, "mz_ring_to_obs: ring depth %d too large", D);
   const dim3 grid((HW + kPix - 1) / kPix, B);
-  MZ_REQUIRE(out_is_bf16 >= 0 && out_is_bf16 <= 3,
-             "mz_ring_to_obs: output format must be 0 (float32), 1 (bf16), 2 (bf16 pairs) or 3 (half)");
+  MZ_REQUIRE(out_is_bf16 >= 0 && out_is_bf16 <= 4,
+             "mz_ring_to_obs: output format must be 0 (float32), 1 (bf16), 2 (bf16 pairs), 3 (half) or 4 (half pairs)");
+  if (out_is_bf16 == 4) {
+    MZ_REQUIRE((3 * D) % 8 == 0 && HW % kPix == 0, "mz_ring_to_obs: the pair format needs 3*D %% 8 == 0 and HW %% 64 == 0");
+    hipLaunchKernelGGL((ring_to_obs_vec_kernel<unsigned short, true, true>), grid, dim3(256), lds, mz::as_stream(stream), ring,
+                       static_cast<unsigned short*>(out), D, HW, newest_slot);
+    return mz::check_launch("mz_ring_to_obs");
+  }
   if (out_is_bf16 == 3) {
     if ((3 * D) % 8 == 0 && HW % kPix == 0)
       hipLaunchKernelGGL((ring_to_obs_vec_kernel<unsigned short, false, true>), grid, dim3(256), lds, mz::as_stream(stream),

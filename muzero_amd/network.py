@@ -17,7 +17,9 @@ Precisions: ``"bf16"`` - bf16 MFMA kernels with float32 accumulation for the ref
 default architecture (throughput); ``"f16"`` - the same kernels with operands in IEEE half (11 significant
 bits instead of 8, the same matrix rate: the policy / value / reward outputs land within the 1e-3 bound of the
 reference's float32 path on its fixtures, hidden states within ~0.5 % of their RMS; values beyond 65 504
-saturate); ``"bf16x3"`` - the same architecture with every float32 value
+saturate); ``"f16x2"`` - float32-accurate at two MFMAs per product: activations as (hi, lo) pairs of IEEE half,
+weights rounded to half once (1e-3 against the reference's float32 path like bf16x3, at 2/3 of its matrix work);
+``"bf16x3"`` - the same architecture with every float32 value
 carried as a (hi, lo) pair of bf16 values and three MFMAs per product: float32-accurate outputs
 (1e-3 against the reference's float32 path) at a third of the bf16 matrix rate; ``"fp32"`` - exact
 float32 kernels on the vector units for any layer shape (validation).
@@ -183,15 +185,16 @@ class Head:
 class MuZeroNetwork:
     def __init__(self, config, precision: str = "bf16", device="cuda", state_dict=None, seed: int = 0,
                  input_hw=(96, 96)):
-        if precision not in ("bf16", "f16", "bf16x3", "fp32"):
-            raise ValueError("precision must be 'bf16', 'f16', 'bf16x3' or 'fp32'")
+        if precision not in ("bf16", "f16", "bf16x3", "f16x2", "fp32"):
+            raise ValueError("precision must be 'bf16', 'f16', 'bf16x3', 'f16x2' or 'fp32'")
         _lib.lib()  # fail now, loudly, if the HIP library is missing
         self.config = config
         self.precision = precision
         self.device = torch.device(device)
-        self.split = precision == "bf16x3"     # activations are (hi, lo) bf16 pairs: [B, 2, H, W, C]
-        self.half = precision == "f16"         # 16-bit operands in IEEE half instead of bf16
-        self.act_dtype = {"fp32": torch.float32, "f16": torch.float16}.get(precision, torch.bfloat16)
+        self.split = precision in ("bf16x3", "f16x2")   # activations are (hi, lo) 16-bit pairs: [B, 2, H, W, C]
+        self.half = precision in ("f16", "f16x2")       # 16-bit operands in IEEE half instead of bf16
+        self.two_products = precision == "f16x2"        # split activations, weights hi only
+        self.act_dtype = {"fp32": torch.float32, "f16": torch.float16, "f16x2": torch.float16}.get(precision, torch.bfloat16)
         self.obs_dtype = {"bf16": torch.bfloat16, "f16": torch.float16}.get(precision, torch.float32)   # what represent() takes
         self.op16 = precision in ("bf16", "f16")   # one 16-bit value per activation: the throughput kernels
         self.A = config.action_space_size
@@ -278,7 +281,7 @@ class MuZeroNetwork:
                                                                   layer.stride)
                 n = mfma.packed_elems(layer.cout, layer.cin)
                 layer.dev["w"] = torch.empty(n, dtype=torch.float16 if self.half else torch.bfloat16, device=self.device)
-                if self.split:   # the part of the float32 weight its bf16 rounding leaves out
+                if self.split and not self.two_products:   # the part of the float32 weight its bf16 rounding leaves out
                     layer.dev["w_lo"] = torch.empty(n, dtype=torch.bfloat16, device=self.device)
 
     def _fold_pack(self, layer: ConvLayer, mode: int, out: torch.Tensor, bias_out=None, rot_depth: int = 0) -> None:
@@ -293,7 +296,7 @@ class MuZeroNetwork:
         """Device copies of the folded weights in the layout the kernels read, into the existing buffers."""
         for layer in self.all_convs():
             self._fold_pack(layer, self._pack_mode, layer.dev["w"], layer.dev["bias"])
-            if self.split:
+            if "w_lo" in layer.dev:
                 self._fold_pack(layer, 1, layer.dev["w_lo"])
             if "rot" in layer.dev:
                 self._fold_pack(layer, self._pack_mode, layer.dev["rot"], None, rot_depth=layer.cin // 3)
@@ -307,7 +310,7 @@ class MuZeroNetwork:
     @property
     def _pack_mode(self) -> int:
         """mz_weights_fold_pack mode of this precision's main weight buffers."""
-        return {"fp32": 2, "f16": 3}.get(self.precision, 0)
+        return {"fp32": 2, "f16": 3, "f16x2": 3}.get(self.precision, 0)
 
     @staticmethod
     def _res(sd, p):
@@ -347,6 +350,11 @@ class MuZeroNetwork:
                 raise NotImplementedError("bf16x3: gather / action / mean are fused only in the 12x12 chain kernel")
             if (H, W, layer.cin, layer.cout, layer.stride) == (12, 12, 256, 256, 1):
                 raise NotImplementedError("bf16x3: 12x12 layers run through the chain kernel")
+            if self.two_products:
+                _lib.call("mz_conv3x3_f16x2", _lib.ptr(x), _lib.ptr(layer.dev["w"]), _lib.ptr(layer.dev["bias"]),
+                          _lib.ptr(residual), _lib.ptr(out), B, H, W, layer.cin, layer.cout, layer.stride,
+                          1 if relu else 0, _lib.current_stream())
+                return
             _lib.call("mz_conv3x3_bf16x3", _lib.ptr(x), _lib.ptr(layer.dev["w"]), _lib.ptr(layer.dev["w_lo"]),
                       _lib.ptr(layer.dev["bias"]), _lib.ptr(residual), _lib.ptr(out), B, H, W, layer.cin, layer.cout,
                       layer.stride, 1 if relu else 0, _lib.current_stream())
@@ -369,7 +377,7 @@ class MuZeroNetwork:
 
     def _chain_ok(self, convs, H, W) -> bool:
         """True when the fused LDS-resident chain kernel serves these layers."""
-        return (self.precision in ("bf16", "f16", "bf16x3") and H == 12 and W == 12 and 1 <= len(convs) <= 20
+        return (self.precision != "fp32" and H == 12 and W == 12 and 1 <= len(convs) <= 20
                 and all(c.cin == 256 and c.cout == 256 and c.stride == 1 for c in convs))
 
     def _mid_blocks(self, plan, i, H, W, last) -> int:
@@ -392,7 +400,7 @@ class MuZeroNetwork:
                 specs.append((first, 1, 0))
             for c1, c2 in blocks:
                 specs += [(c1, 1, 0), (c2, 1, 1)]
-            if self.split:
+            if self.split and not self.two_products:
                 arr = (_lib.ChainLayerX3 * len(specs))()
                 for i, (c, relu, res) in enumerate(specs):
                     arr[i] = _lib.ChainLayerX3(c.dev["w"].data_ptr(), c.dev["w_lo"].data_ptr(),
@@ -403,7 +411,8 @@ class MuZeroNetwork:
                     arr[i] = _lib.ChainLayer(c.dev["w"].data_ptr(), c.dev["bias"].data_ptr(), relu, res)
             cached = self._chains[key] = (arr, len(specs))
         arr, n = cached
-        entry = "mz_conv_chain_bf16x3" if self.split else ("mz_conv_chain_f16" if self.half else "mz_conv_chain_bf16")
+        entry = {"bf16x3": "mz_conv_chain_bf16x3", "f16x2": "mz_conv_chain_f16x2", "f16": "mz_conv_chain_f16"}.get(
+            self.precision, "mz_conv_chain_bf16")
         _lib.call(entry, _lib.ptr(x), _lib.ptr(in_slot), slot_stride, arr, n, _lib.ptr(out),
                   _lib.ptr(self.action_vec) if actions is not None else None, _lib.ptr(actions),
                   _lib.ptr(mean_out), out.shape[0], _lib.current_stream())
@@ -484,7 +493,7 @@ class MuZeroNetwork:
         pairs_in = self.split and rotation is None and obs_nhwc.dim() == 5     # already (hi, lo) pairs
         if pairs_in:
             H, W = obs_nhwc.shape[2], obs_nhwc.shape[3]
-            _lib.expect(obs_nhwc, "observation", torch.bfloat16, (B, 2, H, W, self.cin))
+            _lib.expect(obs_nhwc, "observation", self.act_dtype, (B, 2, H, W, self.cin))
         hh, hw = self.hidden_hw(H, W)
         if not rot_kernel and not pairs_in:
             _lib.expect(obs_nhwc, "observation", self.obs_dtype, (B, H, W, self.cin))
@@ -621,18 +630,19 @@ class MuZeroNetwork:
 
     # ---- the reference's call surface (NCHW float32 in and out)
     def _split(self, x: torch.Tensor) -> torch.Tensor:
-        """float32 [B, ...] -> (hi, lo) bf16 pairs [B, 2, ...]."""
+        """float32 [B, ...] -> (hi, lo) 16-bit pairs [B, 2, ...] (bf16, or IEEE half for f16x2)."""
         x = x.contiguous()
         B, per = x.shape[0], x[0].numel()
-        y = torch.empty((B, 2) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=self.device)
-        _lib.call("mz_split_f32", _lib.ptr(x), _lib.ptr(y), B, per, _lib.current_stream())
+        y = torch.empty((B, 2) + tuple(x.shape[1:]), dtype=self.act_dtype, device=self.device)
+        _lib.call("mz_split_f32_half" if self.half else "mz_split_f32", _lib.ptr(x), _lib.ptr(y), B, per, _lib.current_stream())
         return y
 
     def _join(self, x: torch.Tensor) -> torch.Tensor:
         """(hi, lo) bf16 pairs [B, 2, ...] -> float32 [B, ...]."""
         B, per = x.shape[0], x[0, 0].numel()
         y = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.float32, device=self.device)
-        _lib.call("mz_join_f32", _lib.ptr(x.contiguous()), _lib.ptr(y), B, per, _lib.current_stream())
+        _lib.call("mz_join_f32_half" if self.half else "mz_join_f32", _lib.ptr(x.contiguous()), _lib.ptr(y), B, per,
+                  _lib.current_stream())
         return y
 
     def _to_nhwc(self, x_nchw: torch.Tensor, as_obs: bool = False) -> torch.Tensor:

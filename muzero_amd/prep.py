@@ -85,9 +85,12 @@ class FrameRing:
 
     def observation(self, dtype=torch.bfloat16, out: torch.Tensor = None, pairs: bool = False) -> torch.Tensor:
         """Stacked observation NHWC [B, H, W, 3*depth], oldest frame first, x / 255.  pairs: the float32
-        value as (hi, lo) bf16 pairs [B, 2, H, W, 3*depth] (the bf16x3 precision's input)."""
+        value as (hi, lo) 16-bit pairs [B, 2, H, W, 3*depth] in ``dtype`` - bfloat16 (the bf16x3 precision's
+        input) or float16 (f16x2)."""
         if pairs:
-            dtype, shape, mode = torch.bfloat16, (self.B, 2, self.H, self.W, 3 * self.depth), 2
+            if dtype not in (torch.bfloat16, torch.float16):
+                raise ValueError("pairs are bfloat16 or float16")
+            shape, mode = (self.B, 2, self.H, self.W, 3 * self.depth), 2 if dtype == torch.bfloat16 else 4
         elif dtype in _OBS_FORMAT:
             shape, mode = (self.B, self.H, self.W, 3 * self.depth), _OBS_FORMAT[dtype]
         else:

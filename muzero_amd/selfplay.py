@@ -68,7 +68,7 @@ class SelfPlayWorker:
         """Buffer for the stacked observation in the reference's channel order (allocated on first
         use: the rotating path never needs it)."""
         if self._obs is None:
-            self._obs = torch.empty(*self._obs_shape, dtype=torch.bfloat16 if self.pairs else self.net.obs_dtype,
+            self._obs = torch.empty(*self._obs_shape, dtype=self.net.act_dtype if self.pairs else self.net.obs_dtype,
                                     device=self.net.device)
         return self._obs
 
@@ -94,7 +94,8 @@ class SelfPlayWorker:
         if self.rotating:
             obs, newest = self.ring.rotating_observation()
         else:
-            obs, newest = self.ring.observation(self.net.obs_dtype, out=self.obs, pairs=self.pairs), None
+            dtype = self.net.act_dtype if self.pairs else self.net.obs_dtype
+            obs, newest = self.ring.observation(dtype, out=self.obs, pairs=self.pairs), None
         res: SearchResult = self.mcts.run(obs, self.noise if add_noise else None, rotation=newest)
         actions = select_actions(res.visit_counts, temperature, self.u if temperature != 0 else None)
         return actions, res

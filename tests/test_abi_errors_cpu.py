@@ -20,6 +20,11 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_conv3x3_bf16x3", None, one, one, one, None, one, 1, 96, 96, 96, 256, 2, 1, None)
     _fails("mz_conv3x3_bf16x3", one, one, one, one, None, one, 1, 7, 7, 3, 5, 1, 1, None, match="no kernel")
     _fails("mz_conv_chain_bf16x3", one, None, 0, one, 0, one, None, None, None, 1, None, match="n_layers")
+    _fails("mz_conv3x3_f16x2", None, one, one, None, one, 1, 96, 96, 96, 256, 2, 1, None, match="mz_conv3x3_f16x2: null")
+    _fails("mz_conv3x3_f16x2", one, one, one, None, one, 1, 7, 7, 3, 5, 1, 1, None, match="no kernel")
+    _fails("mz_conv_chain_f16x2", one, None, 0, one, 21, one, None, None, None, 1, None, match="n_layers")
+    _fails("mz_split_f32_half", None, one, 1, 1, None, match="bad arguments")
+    _fails("mz_join_f32_half", one, None, 1, 1, None, match="bad arguments")
     _fails("mz_weights_fold_pack", one, None, None, None, None, None, 1e-5, 256, 256, 256, 7, 0, 0, one, None, None,
            match="mode")
     _fails("mz_weights_fold_pack", one, None, one, None, None, None, 1e-5, 256, 256, 256, 0, 0, 0, one, None, None,

@@ -128,7 +128,7 @@ def test_selfplay_worker_evaluate_mode_and_temperature_zero():
 
 
 @pytest.mark.parametrize("A,B,precision", [(6, 256, "bf16"), (18, 1024, "bf16"), (9, 4096, "bf16"), (18, 1024, "bf16x3"),
-                                           (18, 1024, "f16")])
+                                           (18, 1024, "f16"), (18, 1024, "f16x2")])
 def test_full_size_search_properties_and_sampled_replay(A, B, precision):
     """The benchmark configurations at their full sizes, through the calls the benchmark makes (for bf16 the
     ROTATING observation and the first convolution's permuted weight copies, after enough moves to wrap the ring):
@@ -156,7 +156,8 @@ def test_full_size_search_properties_and_sampled_replay(A, B, precision):
         obs, newest = worker.ring.rotating_observation()
         assert newest == 1
     else:
-        obs, newest = worker.ring.observation(net.obs_dtype, out=worker.obs, pairs=worker.pairs), None
+        obs, newest = worker.ring.observation(net.act_dtype if worker.pairs else net.obs_dtype, out=worker.obs,
+                                              pairs=worker.pairs), None
     pri0, val0 = net.initial_to_pool(obs, m.pool[0], newest)
     p0 = pri0[idx].cpu().numpy()
     # root priors / values of four sampled games against the float32 CPU networks on the stacked observation
@@ -168,7 +169,7 @@ def test_full_size_search_properties_and_sampled_replay(A, B, precision):
     with torch.no_grad():
         _, p_ref, v_ref = ref.initial(torch.tensor(oprep.prepare(stacked)))
     want = torch.softmax(p_ref, dim=1).numpy()
-    tol = {"bf16": 0.02, "f16": 0.003}.get(precision, 1e-3)
+    tol = {"bf16": 0.02, "f16": 0.003}.get(precision, 1e-3)       # bf16x3, f16x2: float32-accurate
     assert np.abs(p0[:4] - want).max() <= tol * want.max(), np.abs(p0[:4] - want).max()
     m.trees.root_init(pri0, worker.noise, cfg.root_exploration_fraction)
     m.trees.select()

@@ -26,11 +26,12 @@ def test_small_config_network_matches_reference_fixture():
     assert o0.reward is None
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("A", [6, 18])
 def test_full_size_network_fp32_matches_reference_fixture(A, precision):
-    """Both float32-accurate precisions against the reference's own outputs: "fp32" (vector-unit fmaf
-    kernels) and "bf16x3" (three bf16 MFMAs per product on (hi, lo) pairs), same 1e-3 bound."""
+    """The float32-accurate precisions against the reference's own outputs: "fp32" (vector-unit fmaf
+    kernels), "bf16x3" (three bf16 MFMAs per product on (hi, lo) pairs) and "f16x2" (two half MFMAs per product:
+    activations as half pairs, weights rounded to half), same 1e-3 bound."""
     from muzero_amd.network import MuZeroNetwork
     from muzero_amd.prep import prepare_observation
     from oracle import nets as onets

@@ -38,7 +38,7 @@ def _replay_with_device_outputs(trees_log, priors0, noise, sims, wave, cfg):
     return root, bounds
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("A,wave,noisy", [(6, 1, True), (18, 1, False), (6, 5, True)])
 def test_batched_search_matches_oracle(A, wave, noisy, precision):
     """fp32: exact float32 kernels on the vector units; bf16x3: the float32-accurate matrix-core path.

@@ -34,7 +34,7 @@ for _ in range(31):
 noise = torch.from_numpy(rng.dirichlet(np.full(A, 0.3), size=B)).cuda()
 res = {}
 for name, precision, rotating in (("fp32", "fp32", False), ("bf16", "bf16", False), ("bf16_rotating", "bf16", True),
-                                  ("f16", "f16", False), ("bf16x3", "bf16x3", False)):
+                                  ("f16", "f16", False), ("bf16x3", "bf16x3", False), ("f16x2", "f16x2", False)):
     net = MuZeroNetwork(cfg, precision=precision, state_dict=sd)
     m = BatchedMCTS(cfg, net, B, sims)
     if rotating:
@@ -58,4 +58,4 @@ def compare(a, b):
 
 print(json.dumps({"games": B, "actions": A, "sims": sims, "seed": seed,
                   "pairs": [compare("fp32", "bf16"), compare("fp32", "bf16_rotating"), compare("bf16", "bf16_rotating"),
-                            compare("fp32", "f16"), compare("fp32", "bf16x3")]}))
+                            compare("fp32", "f16"), compare("fp32", "bf16x3"), compare("fp32", "f16x2")]}))
