@@ -332,3 +332,79 @@ def test_pair_observation_for_the_float32_accurate_precision():
     other = BatchedMCTS(cfg, net, B, 8).run(f32, worker.noise)
     assert np.array_equal(other.visit_counts.cpu().numpy(), v)
     assert np.array_equal(other.root_values.cpu().numpy(), res.root_values.cpu().numpy())
+
+
+def test_half_results_saturate_instead_of_overflowing():
+    """IEEE-half kernels store a result beyond the largest finite half as 65 504 (-65 504), never as infinity:
+    single trunk layer and the two-image chain, with and without ReLU."""
+    from muzero_amd import _lib, mfma
+    B = 300                                     # more images than compute units: the chain takes the two-image kernel
+    w = torch.full((256, 256, 3, 3), 4.0)
+    w[1::2] = -4.0                              # odd output channels: large negative sums
+    wp = mfma.pack_weights(w, 256, torch.float16).cuda()
+    bias = torch.zeros(256, device="cuda")
+    x = torch.full((B, 12, 12, 256), 32.0, dtype=torch.float16, device="cuda")     # |sum| >= 4 taps * 256 * 32 * 4 = 131 072
+
+    class _L:
+        cin, cout, stride = 256, 256, 1
+        dev = {"w": wp, "bias": bias}
+    out = torch.empty_like(x)
+    mfma.conv(_L, x, out, B, 12, 12, False, None, None, 0, None, None, None, half=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert float(out[..., 0::2].min()) == 65504.0 and float(out[..., 1::2].max()) == -65504.0
+    arr = (_lib.ChainLayer * 1)()
+    arr[0] = _lib.ChainLayer(wp.data_ptr(), bias.data_ptr(), 0, 0)
+    out2 = torch.empty_like(x)
+    mean = torch.empty(B, 256, device="cuda")
+    _lib.call("mz_conv_chain_f16", _lib.ptr(x), None, 0, arr, 1, _lib.ptr(out2), None, None, _lib.ptr(mean), B,
+              _lib.current_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    arr[0] = _lib.ChainLayer(wp.data_ptr(), bias.data_ptr(), 1, 0)            # with ReLU: the negative half is zero
+    _lib.call("mz_conv_chain_f16", _lib.ptr(x), None, 0, arr, 1, _lib.ptr(out2), None, None, _lib.ptr(mean), B,
+              _lib.current_stream())
+    torch.cuda.synchronize()
+    assert float(out2[..., 0::2].min()) == 65504.0 and float(out2[..., 1::2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x2"])
+def test_half_precisions_through_the_worker_and_a_captured_graph(precision):
+    """The IEEE-half precisions on the self-play worker's own path: f16 reads the rotating half observation (first
+    convolution through permuted weight copies), f16x2 the (hi, lo) half pairs, which equal the split of the float32
+    observation bit for bit; a HIP graph of the search replays the eager result exactly while the ring advances."""
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.network import MuZeroNetwork, init_state_dict
+    from muzero_amd.selfplay import SelfPlayWorker, SyntheticEnv
+    cfg = MuZeroConfig()
+    cfg.action_space_size, cfg.num_simulations = 6, 8
+    net = MuZeroNetwork(cfg, precision=precision, state_dict=init_state_dict(cfg, seed=2, randomize_bn=True))
+    B = 5
+    worker = SelfPlayWorker(cfg, net, B, 8)
+    assert worker.rotating == (precision == "f16") and worker.pairs == (precision == "f16x2")
+    env = SyntheticEnv(B, device="cuda", pool=8)
+    worker.reset(env.reset())
+    for _ in range(33):
+        worker.ring.push(env.step())
+    worker.draw_randomness()
+    if precision == "f16x2":
+        pairs = worker.ring.observation(torch.float16, pairs=True)
+        want = net._split(worker.ring.observation(torch.float32))
+        assert pairs.dtype == torch.float16 and torch.equal(pairs.view(torch.int16), want.view(torch.int16))
+        obs, rotation, rot_dev = pairs, None, None
+    else:
+        obs, rotation = worker.ring.rotating_observation()
+        assert obs.dtype == torch.float16
+        rot_dev = worker.ring.newest_dev
+    replay = worker.mcts.capture(obs, worker.noise, rotation=rot_dev) if precision == "f16" else \
+        worker.mcts.capture(worker.obs, worker.noise)
+    for _ in range(3):
+        actions, res = worker.step(env.step(), temperature=0, add_noise=True)
+        v, q = res.visit_counts.cpu().numpy().copy(), res.root_values.cpu().numpy().copy()
+        assert (v.sum(1) == 8).all() and np.isfinite(q).all()
+        worker.mcts.visits.zero_()
+        if precision == "f16x2":
+            worker.ring.observation(torch.float16, out=worker.obs, pairs=True)
+        r2 = replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(r2.visit_counts.cpu().numpy(), v) and np.array_equal(r2.root_values.cpu().numpy(), q)
