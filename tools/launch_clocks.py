@@ -78,23 +78,25 @@ def spans(name):
 
 spans("in the search")
 
-# the same kernel alone, back to back
+# the same kernel alone, back to back: random data, then all-zero data (same instruction stream, no operand toggling)
 from muzero_amd import mfma  # noqa: E402
-for layers in (5, 18):
-    keep = []
-    arr = (_lib.ChainLayer * layers)()
-    for l in range(layers):
-        w = mfma.pack_weights(torch.randn(256, 256, 3, 3) / 48.0, 256).cuda()
-        b = (torch.randn(256) * 0.1).cuda()
-        keep += [w, b]
-        arr[l] = _lib.ChainLayer(w.data_ptr(), b.data_ptr(), 1, l % 2)
-    x = torch.randn(B, 12, 12, 256, device="cuda").to(torch.bfloat16)
-    out = torch.empty_like(x)
-    mean = torch.empty(B, 256, device="cuda")
-    for _ in range(60):
-        _lib.call("mz_conv_chain_bf16", _lib.ptr(x), None, 0, arr, layers, _lib.ptr(out), None, None, _lib.ptr(mean), B,
-                  _lib.current_stream())
-    torch.cuda.synchronize()
-    n0 = n
-    n, r = records(n0)
-    report("alone, back to back", r[10:])
+for data in ("random", "zeros"):
+    for layers in (5, 18):
+        keep = []
+        arr = (_lib.ChainLayer * layers)()
+        for l in range(layers):
+            wt = torch.randn(256, 256, 3, 3) / 48.0 if data == "random" else torch.zeros(256, 256, 3, 3)
+            w = mfma.pack_weights(wt, 256).cuda()
+            b = (torch.randn(256) * 0.1).cuda() if data == "random" else torch.zeros(256, device="cuda")
+            keep += [w, b]
+            arr[l] = _lib.ChainLayer(w.data_ptr(), b.data_ptr(), 1, l % 2)
+        x = (torch.randn(B, 12, 12, 256, device="cuda") if data == "random" else torch.zeros(B, 12, 12, 256, device="cuda")).to(torch.bfloat16)
+        out = torch.empty_like(x)
+        mean = torch.empty(B, 256, device="cuda")
+        for _ in range(60):
+            _lib.call("mz_conv_chain_bf16", _lib.ptr(x), None, 0, arr, layers, _lib.ptr(out), None, None, _lib.ptr(mean), B,
+                      _lib.current_stream())
+        torch.cuda.synchronize()
+        n0 = n
+        n, r = records(n0)
+        report(f"alone, back to back, {data} data", r[10:])
