@@ -458,15 +458,21 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
                      const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
                      double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream);
 
-/* Weight gradient of a 3x3 convolution (padding 1, stride 1) for the unrolled training step (compute_losses'
- * backward pass, train.py:303-308): dw float [Cout][Cin][3][3] = sum over images and pixels of
- * grad_out[n][y][x][co] * x[n][y+ky-1][x+kx-1][ci]; grad_out and x bf16 NHWC, float32 accumulation; dbias
- * (optional, float [Cout]) = sum over images and pixels of grad_out, from the same pass.  A kernel
- * exists for the 12x12, 256->256 shape (23 of the 31 convolutions); other shapes return MZ_E_ARG.  workspace:
- * caller-owned device memory of at least mz_conv_wgrad_workspace_bytes(B) bytes (partial sums of the image
- * shares); dw and workspace 16-byte aligned.  The matching data gradient is mz_conv3x3_bf16 applied to grad_out with weights packed by
- * mz_weights_fold_pack(transpose = 1) and a zero bias. */
+/* Weight gradient of a 3x3 convolution (padding 1) for the unrolled training step (compute_losses' backward
+ * pass, train.py:303-308): dw float [Cout][Cin][3][3] = sum over images and output pixels of
+ * grad_out[n][y][x][co] * x[n][s*y+ky-1][s*x+kx-1][ci]; grad_out (bf16 NHWC [B][H/s][W/s][Cout]) and x (bf16 NHWC
+ * [B][H][W][Cin]), float32 accumulation; dbias (optional, float [Cout]) = sum over images and pixels of grad_out,
+ * from the same pass.  H, W: the layer's INPUT size.  Kernels exist for the reference architecture's layer shapes
+ * (model.py:165, :182, :146-148), the stride being the layer's: 12x12 256->256 (s = 1, 23 of the 31
+ * convolutions), 96x96 96->256 (s = 2), 48x48 256->128 (s = 2), 24x24 128->128 (s = 1), 24x24 128->256 (s = 2);
+ * other shapes return MZ_E_ARG.  workspace: caller-owned device memory of at least
+ * mz_conv_wgrad_workspace_bytes_for(B, H, W, Cin, Cout) bytes (partial sums of the shares of the batch; 0 = no
+ * kernel for the shape; mz_conv_wgrad_workspace_bytes(B) is the 12x12 shape's); dw and workspace 16-byte aligned;
+ * a tensor at most 4 GiB.  The matching data gradient of a stride-1 layer is mz_conv3x3_bf16 applied to grad_out
+ * with weights packed by mz_weights_fold_pack(transpose = 1) and a zero bias; of a stride-2 layer,
+ * mz_conv_dgrad_s2_bf16. */
 int64_t mz_conv_wgrad_workspace_bytes(int32_t B);
+int64_t mz_conv_wgrad_workspace_bytes_for(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream);

@@ -1,9 +1,10 @@
-// Weight gradient of the 12x12 256->256 3x3 convolution (the shape of 23 of the network's 31
-// convolutions) for the unrolled training step (compute_losses / update_weights, train.py:295-431):
-//     dW[co][ci][ky][kx] = sum over images n and pixels (y, x) of
-//                          gout[n][y][x][co] * x[n][y + ky - 1][x + kx - 1][ci]      (zero outside the image)
-// bf16 operands, float32 accumulation on the matrix cores.  The data gradient needs no kernel of its
-// own: it is the forward convolution of gout with the transposed, mirrored weights
+// Weight gradient of the 3x3 convolutions for the unrolled training step (compute_losses / update_weights,
+// train.py:295-431); first the 12x12 256->256 layer (the shape of 23 of the network's 31 convolutions), then
+// - same scheme, a band of output rows at a time - the four other shapes of the representation network:
+//     dW[co][ci][ky][kx] = sum over images n and output pixels (y, x) of
+//                          gout[n][y][x][co] * x[n][s y + ky - 1][s x + kx - 1][ci]  (zero outside the image)
+// bf16 operands, float32 accumulation on the matrix cores.  The data gradient of a stride-1 layer needs no
+// kernel of its own: it is the forward convolution of gout with the transposed, mirrored weights
 // (mz_weights_fold_pack with transpose = 1, then mz_conv3x3_bf16).
 //
 // As a GEMM the reduction runs over pixels, which are the SLOW index of both NHWC operands; gfx950's
@@ -42,6 +43,14 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ s16x4 read_tr(int lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+}
+
+// acc + (operand tile `which` of af)^T x ones: the column sums of that tile's 16 channels over the k-step's 32
+// pixels, in every column of the result.  `which` is uniform in the wavefront.
+__device__ __forceinline__ f32x4 column_sums(s16x8 a0, s16x8 a1, s16x8 a2, s16x8 a3, int which, f32x4 acc) {
+  const s16x8 ones = s16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+  const s16x8 a = which == 0 ? a0 : which == 1 ? a1 : which == 2 ? a2 : a3;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, ones), acc, 0, 0, 0);
 }
 
 // The images may come in several equally sized segments (the same layer applied at several unroll steps:
@@ -106,8 +115,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool want_db = db_partial != nullptr && (tile & 1) == 0;  // one of the two input-channel tiles does it
-  float dbacc = 0.f;
+  // bias gradient = column sums of gout = gout^T x (a vector of ones): one more MFMA per k-step in four of the
+  // wavefronts of one of the two input-channel tiles (wavefront w < 4 takes the 16 channels of operand tile w)
+  const bool want_db = db_partial != nullptr && (tile & 1) == 0 && wave < 4;
+  f32x4 dbv = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
   // lane 4q + p4 of a 16-lane group supplies row q, columns 4 p4 .. 4 p4 + 3 of the block it reads
@@ -128,11 +139,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
     if (x4_ok) *reinterpret_cast<uint4*>(xs + xd4) = x4;
     __syncthreads();
     if (n + shares < n_images) MZ_LOAD_IMAGE(n + shares);  // travels while this image is multiplied
-    if (want_db) {  // bias gradient = column sums of gout: 8 row groups x 64 channels of the staged slice
-#pragma unroll
-      for (int r = tid >> 6; r < kPix; r += 8)
-        dbacc += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(gs + r * kGRow + (tid & 63) * 2) << 16);
-    }
 #pragma unroll 1
     for (int ks = 0; ks < kKSteps; ++ks) {
       // the two pixel rows this lane addresses in this k-step, and where their tap-(0,0) neighbours sit in xs
@@ -148,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
         const s16x4 hi = read_tr(g_lane + (ks * 32 + 16) * kGRow + c * 32);
         af[c] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+      if (want_db) dbv = column_sums(af[0], af[1], af[2], af[3], wave, dbv);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int toff = ((t / 3) * kPadSide + t % 3) * kXRow;
@@ -163,23 +170,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
     __syncthreads();  // everyone has read this image
   }
 
-  if (want_db) {  // (the loop's last barrier has passed: the staging area is free)
-    float* red = reinterpret_cast<float*>(lds);
-    red[tid] = dbacc;
-    __syncthreads();
-    if (tid < 64) {
-      float s = 0.f;
+  if (want_db && (lane & 15) == 0) {  // every column of the product holds the sums; rows 4 kq .. 4 kq + 3
 #pragma unroll
-      for (int g = 0; g < 8; ++g) s += red[g * 64 + tid];
-      db_partial[share * kCh + co0 + tid] = s;
-    }
+    for (int r = 0; r < 4; ++r) db_partial[share * kCh + co0 + wave * 16 + 4 * kq + r] = dbv[r];
   }
   // partial[share][co][ci][tap] (the layout of dW itself).  A lane holds rows (co) 4 kq .. 4 kq + 3 of column
   // (ci) lane % 16: for one accumulator row r the wavefront owns, in each of 4 rows of dW, 16 ci x 9 taps = 576
-  // consecutive bytes.  They pass through a wavefront-private piece of LDS (the staging area is free by now; the
-  // first 2 KB may still hold the bias sums) so that they leave as whole 16-byte units of consecutive addresses.
+  // consecutive bytes.  They pass through a wavefront-private piece of LDS (the staging area is free by now)
+  // so that they leave as whole 16-byte units of consecutive addresses.
   float* dst = partial + (long)share * 9 * kCh * kCh;
-  float* tr = reinterpret_cast<float*>(lds + 2048) + wave * 576;
+  float* tr = reinterpret_cast<float*>(lds) + wave * 576;
   const int l16 = lane & 15;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -200,32 +200,301 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
     }
 }
 
-// dW = sum over shares of partial[share], in share order; four consecutive floats per thread
+// dW = sum over shares of partial[share]: a workgroup owns 64 float4 columns of dW; its 16 wavefronts add up every
+// 16th share each (up to eight loads in flight per thread: with 128 shares the whole read is one round trip),
+// then wavefront 0 adds the 16 sums in a fixed order.  dw4: float4s of dW (the grid covers them in 64s), cout:
+// output channels (at most 256).
 constexpr int kDw4 = 9 * kCh * kCh / 4;
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float4* __restrict__ partial, int shares,
-                                                          float4* __restrict__ dw, const float* __restrict__ db_partial,
-                                                          float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // the grid covers kDw4 exactly
-  if (db && blockIdx.x == 0) {
-    float s = 0.f;
-    for (int g = 0; g < shares; ++g) s += db_partial[g * kCh + threadIdx.x];
-    db[threadIdx.x] = s;
+constexpr int kRedGroups = 16;
+__global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_kernel(const float4* __restrict__ partial, int shares,
+                                                                      float4* __restrict__ dw,
+                                                                      const float* __restrict__ db_partial,
+                                                                      float* __restrict__ db, int dw4, int cout) {
+  __shared__ float4 part[kRedGroups - 1][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  if (db && blockIdx.x == 0) {  // the bias gradient: four threads per channel, every fourth share each
+    __shared__ float dbs[4][256];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    float t = 0.f;
+    if (c < cout) {
+      int g = q;
+      for (; g + 28 < shares; g += 32) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = db_partial[(g + 4 * k) * cout + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+      }
+      for (; g < shares; g += 4) t += db_partial[g * cout + c];
+    }
+    dbs[q][c] = t;
+    __syncthreads();
+    if (q == 0 && c < cout) db[c] = (dbs[0][c] + dbs[1][c]) + (dbs[2][c] + dbs[3][c]);
   }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* p = partial + i;
-  int g = 0;
-  for (; g + 8 <= shares; g += 8) {  // eight loads in flight per thread
-    float4 v[8];
+  if (col < dw4) {
+    const float4* p = partial + col;
+    int g = grp;
+    for (; g + 7 * kRedGroups < shares; g += 8 * kRedGroups) {
+      float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = p[(long)(g + k) * kDw4];
+      for (int k = 0; k < 8; ++k) v[k] = p[(long)(g + kRedGroups * k) * dw4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+      for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+    }
+    for (; g < shares; g += kRedGroups) {
+      const float4 v = p[(long)g * dw4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  for (; g < shares; ++g) {
-    const float4 v = p[(long)g * kDw4];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (grp > 0) part[grp - 1][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < dw4) {
+#pragma unroll
+    for (int k = 0; k < kRedGroups - 1; ++k) {
+      const float4 v = part[k][threadIdx.x];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dw[col] = s;
   }
-  dw[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The other layer shapes (model.py:165, :182): the same scheme with the image cut into bands of R output rows.
+// A workgroup owns a (64 WCO) x (16 WCI) x 9 tile of dW - its WCO x WCI = 8 wavefronts one 64 (co) x 16 (ci) x 9
+// piece each - and every `shares`-th unit (image, band).  Per unit it stages the band of gout (R WO pixels x CoT
+// channels) and the rows of x the band's taps touch (S (R - 1) + 3 rows of S (WO - 1) + 3 pixels incl. the zero
+// halo, x CiT channels); the next unit travels in registers meanwhile.  Row pitches: consecutive output pixels
+// are S window pixels apart, so S times the x pitch (and the gout pitch) is an odd multiple of 32 bytes mod 256 -
+// the 8 rows a 32-lane half reads through ds_read_b64_tr_b16 fall on 8 different bank groups.
+template <int HO_, int WO_, int S_, int CIN_, int COUT_, int WCO_, int WCI_, int R_>
+struct WgShape {
+  static constexpr int HO = HO_, WO = WO_, S = S_, CIN = CIN_, COUT = COUT_, WCO = WCO_, WCI = WCI_, R = R_;
+  static constexpr int H = HO * S, W = WO * S;  // input size (even sizes: (H - 1) / S + 1 == H / S)
+  static constexpr int CoT = 64 * WCO, CiT = 16 * WCI;
+  static constexpr int TILES_CO = COUT / CoT, TILES_CI = CIN / CiT, TILES = TILES_CO * TILES_CI;
+  static constexpr int BANDS = HO / R, PIX = R * WO, KSTEPS = (PIX + 31) / 32, GROWS = KSTEPS * 32;
+  static constexpr int XR = S * (R - 1) + 3, XW = S * (WO - 1) + 3;
+  static constexpr int GROW = CoT * 2 + 32, XROW = CiT * 2 + (S == 2 ? 16 : 32);
+  static constexpr int GBYTES = GROWS * GROW, XBYTES = XR * XW * XROW, LDS = GBYTES + XBYTES;
+  static constexpr int GUPP = CoT / 8, XUPP = CiT / 8;             // 16-byte units per pixel of a slice
+  static constexpr int GUNITS = PIX * GUPP, XUNITS = XR * W * XUPP;
+  static constexpr int GROUNDS = (GUNITS + 511) / 512, XROUNDS = (XUNITS + 511) / 512;
+  static constexpr int DW4 = COUT * CIN * 9 / 4;
+  static_assert(WCO * WCI == 8 && COUT % CoT == 0 && CIN % CiT == 0 && HO % R == 0, "tiling");
+  static_assert(LDS <= 160 * 1024 && LDS >= 8 * 576 * 4, "staging area");
+};
+//                       HO  WO  S  CIN COUT WCO WCI R
+using WgStem  = WgShape<48, 48, 2,  96, 256, 4, 2, 2>;   // representation.conv1: 96x96x96 -> 48x48x256
+using WgDown0 = WgShape<24, 24, 2, 256, 128, 2, 4, 4>;   // downsample.0.conv:    48x48x256 -> 24x24x128
+using WgMid   = WgShape<24, 24, 1, 128, 128, 1, 8, 6>;   // downsample.0.blocks:  24x24x128 -> 24x24x128
+using WgDown1 = WgShape<12, 12, 2, 128, 256, 2, 4, 4>;   // downsample.1.conv:    24x24x128 -> 12x12x256
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_band_kernel(const __bf16* __restrict__ gout,
+                                                                const __bf16* __restrict__ x, int n_images, int shares,
+                                                                float* __restrict__ partial,
+                                                                float* __restrict__ db_partial) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* gs = lds;
+  char* xs = lds + C::GBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave / C::WCI, wci = wave % C::WCI;
+  // consecutive workgroups land on consecutive XCDs: the tiles of one share sit 8 ids apart, i.e. on one XCD,
+  // and read the same bands at about the same time (one fetch into that XCD's L2 serves all of them)
+  const int tile = (blockIdx.x >> 3) % C::TILES;
+  const int share = (blockIdx.x / (8 * C::TILES)) * 8 + (blockIdx.x & 7);
+  if (share >= shares) return;
+  const int co0 = (tile / C::TILES_CI) * C::CoT, ci0 = (tile % C::TILES_CI) * C::CiT;
+  const int kq = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const int units = n_images * C::BANDS;
+
+  for (int i = tid; i < C::LDS / 16; i += 512) *reinterpret_cast<uint4*>(lds + i * 16) = make_uint4(0, 0, 0, 0);
+
+  // Staging loads are buffer loads: one descriptor per tensor, the unit's base (its first window row inside the
+  // image) in a scalar register, the thread's own offsets fixed for the whole launch.  The window row above the
+  // first band gets a negative offset - as an unsigned number past the end of the buffer, for which the hardware
+  // returns zeros without touching memory; the row below the last band (stride 1 only) is pointed there by hand.
+  constexpr unsigned kOutside = 0xffffff00u;
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(gout), 0, (unsigned)n_images * (unsigned)(C::HO * C::WO * C::COUT * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x), 0, (unsigned)n_images * (unsigned)(C::H * C::W * C::CIN * 2), 0x00020000);
+  unsigned goff[C::GROUNDS], xoff[C::XROUNDS];
+#pragma unroll
+  for (int j = 0; j < C::GROUNDS; ++j) {
+    int v = tid + 512 * j;
+    v = v < C::GUNITS ? v : C::GUNITS - 1;
+    goff[j] = (unsigned)(((v / C::GUPP) * C::COUT + co0 + (v % C::GUPP) * 8) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < C::XROUNDS; ++j) {
+    int v = tid + 512 * j;
+    v = v < C::XUNITS ? v : C::XUNITS - 1;
+    const int pl = v / C::XUPP, r = pl / C::W, ix = pl - r * C::W;
+    xoff[j] = (unsigned)(((r * C::W + ix) * C::CIN + ci0 + (v % C::XUPP) * 8) * 2);
+  }
+  u32x4_t gv[C::GROUNDS], xv[C::XROUNDS];
+  auto load_unit = [&](int u) __attribute__((always_inline)) {
+    const int n = u / C::BANDS, band = u - n * C::BANDS;
+    const int gbase = __builtin_amdgcn_readfirstlane((int)((unsigned)((n * C::HO + band * C::R) * C::WO) * (unsigned)(C::COUT * 2)));
+    const int top = band == 0 ? 0 : C::S * band * C::R - 1;   // first window row that exists
+    const int xbase = __builtin_amdgcn_readfirstlane((int)((unsigned)(n * C::H + top) * (unsigned)(C::W * C::CIN * 2)));
+    const unsigned shift = band == 0 ? (unsigned)(C::W * C::CIN * 2) : 0u;   // first band: window row r is image row r - 1
+#pragma unroll
+    for (int j = 0; j < C::GROUNDS; ++j) gv[j] = __builtin_amdgcn_raw_buffer_load_b128(grs, goff[j], gbase, 0);
+#pragma unroll
+    for (int j = 0; j < C::XROUNDS; ++j) {
+      unsigned o = xoff[j] - shift;
+      if constexpr (C::S == 1) {   // the window's last row of the last band lies below the image
+        const int v = tid + 512 * j;
+        const int r = (v < C::XUNITS ? v : C::XUNITS - 1) / (C::XUPP * C::W);
+        o = (band == C::BANDS - 1 && r == C::XR - 1) ? kOutside : o;
+      }
+      xv[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, o, xbase, 0);
+    }
+  };
+  auto store_unit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < C::GROUNDS; ++j) {
+      const int v = tid + 512 * j;
+      if (v < C::GUNITS) *reinterpret_cast<u32x4_t*>(gs + (v / C::GUPP) * C::GROW + (v % C::GUPP) * 16) = gv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < C::XROUNDS; ++j) {
+      const int v = tid + 512 * j;
+      if (v < C::XUNITS) {
+        const int pl = v / C::XUPP, r = pl / C::W, ix = pl - r * C::W;
+        *reinterpret_cast<u32x4_t*>(xs + (r * C::XW + ix + 1) * C::XROW + (v % C::XUPP) * 16) = xv[j];
+      }
+    }
+  };
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient as in the 12x12 kernel: among the WCI wavefronts that share gout's columns, wavefront wci takes
+  // NDB of the four operand tiles (one input-channel tile per output-channel tile does it)
+  constexpr int NDB = C::WCI >= 4 ? 1 : 4 / C::WCI;
+  const bool want_db = db_partial != nullptr && tile % C::TILES_CI == 0 && wci * NDB < 4;
+  f32x4 dbv[NDB];
+#pragma unroll
+  for (int i = 0; i < NDB; ++i) dbv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lds_base = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  const int g_lane = lds_base + (4 * kq + q) * C::GROW + wco * 128 + p4 * 8;  // + pixel0 * GROW + co tile * 32
+  const int x_col = lds_base + C::GBYTES + wci * 32 + p4 * 8;                 // + window pixel * XROW
+
+  int u = share;
+  if (u < units) load_unit(u);
+  __syncthreads();  // zeroing done
+  for (; u < units; u += shares) {
+    store_unit();
+    __syncthreads();
+    if (u + shares < units) load_unit(u + shares);  // travels while this unit is multiplied
+#pragma unroll 1
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      const int pa = ks * 32 + 4 * kq + q, pb = pa + 16;
+      const int pya = pa / C::WO, pxa = pa - pya * C::WO;
+      const int pyb = pb / C::WO, pxb = pb - pyb * C::WO;
+      // pixels past the band: gout is zero there, any window pixel will do
+      const int xa = x_col + (pa < C::PIX ? (C::S * pya * C::XW + C::S * pxa) : 0) * C::XROW;
+      const int xb = x_col + (pb < C::PIX ? (C::S * pyb * C::XW + C::S * pxb) : 0) * C::XROW;
+      s16x8 af[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const s16x4 lo = read_tr(g_lane + ks * 32 * C::GROW + c * 32);
+        const s16x4 hi = read_tr(g_lane + (ks * 32 + 16) * C::GROW + c * 32);
+        af[c] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      if (want_db) {
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) dbv[i] = column_sums(af[0], af[1], af[2], af[3], wci * NDB + i, dbv[i]);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int toff = ((t / 3) * C::XW + t % 3) * C::XROW;
+        const s16x4 lo = read_tr(xa + toff);
+        const s16x4 hi = read_tr(xb + toff);
+        const s16x8 bfr = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[c]),
+                                                              __builtin_bit_cast(bf16x8, bfr), acc[c][t], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // everyone has read this unit
+  }
+
+  if (want_db && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        db_partial[share * C::COUT + co0 + wco * 64 + (wci * NDB + i) * 16 + 4 * kq + r] = dbv[i][r];
+  }
+  // partial[share][co][ci][tap], through a wavefront-private piece of LDS as in the 12x12 kernel
+  float* dst = partial + (long)share * 9 * C::COUT * C::CIN;
+  float* tr = reinterpret_cast<float*>(lds) + wave * 576;
+  const int l16 = lane & 15;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) tr[kq * 144 + l16 * 9 + t] = acc[c][t][r];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int f = lane + 64 * j;  // float4 index within the 4 x 144 floats
+        if (f < 144) {
+          const int row = f / 36, col4 = f - row * 36;
+          const float4 v = *reinterpret_cast<const float4*>(tr + row * 144 + col4 * 4);
+          const long o = ((long)(co0 + wco * 64 + c * 16 + 4 * row + r) * C::CIN + ci0 + wci * 16) * 9 + col4 * 4;
+          *reinterpret_cast<float4*>(dst + o) = v;
+        }
+      }
+    }
+}
+
+template <class C>
+bool wg_matches(int H, int W, int Cin, int Cout) { return H == C::H && W == C::W && Cin == C::CIN && Cout == C::COUT; }
+
+// Workgroups of one launch: shares x TILES, one per compute unit at most (a second workgroup does not fit beside
+// the first and would run after it).  Shares go to the XCDs in turn (see the kernel), so a whole number of
+// rounds of 8 keeps every XCD within its own compute units.
+template <class C>
+int wg_shares(int B) {
+  int by_cu = mz::compute_units() / C::TILES;
+  if (by_cu >= 8) by_cu -= by_cu % 8;
+  const int units = B * C::BANDS;
+  const int s = units < by_cu ? units : by_cu;
+  return s < 1 ? 1 : s;
+}
+
+template <class C>
+int64_t wg_workspace(int B) { return (int64_t)wg_shares<C>(B) * (9 * C::COUT * C::CIN + C::COUT) * 4; }
+
+template <class C>
+int wg_launch(const void* gout, const void* x, int B, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
+              hipStream_t s) {
+  MZ_REQUIRE(workspace_bytes >= wg_workspace<C>(B), "mz_conv_wgrad_bf16: workspace of %lld bytes, %lld needed",
+             (long long)workspace_bytes, (long long)wg_workspace<C>(B));
+  MZ_REQUIRE((int64_t)B * C::H * C::W * C::CIN * 2 < (1LL << 32) && (int64_t)B * C::HO * C::WO * C::COUT * 2 < (1LL << 32),
+             "mz_conv_wgrad_bf16: a tensor of %d images exceeds 4 GiB", B);
+  static bool configured[mz::kMaxDevices] = {false};
+  auto kern = conv_wgrad_band_kernel<C>;
+  if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), C::LDS, configured, "conv_wgrad_band"))
+    return rc;
+  const int shares = wg_shares<C>(B);
+  float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * C::COUT * C::CIN : nullptr;
+  hipLaunchKernelGGL(kern, dim3((shares + 7) / 8 * 8 * C::TILES), dim3(512), C::LDS, s, static_cast<const __bf16*>(gout),
+                     static_cast<const __bf16*>(x), B, shares, static_cast<float*>(workspace), dbp);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C::DW4 + 63) / 64), dim3(64 * kRedGroups), 0, s, static_cast<const float4*>(workspace),
+                     shares, reinterpret_cast<float4*>(dw), dbp, dbias, C::DW4, C::COUT);
+  return mz::check_launch("mz_conv_wgrad_bf16");
 }
 
 }  // namespace
@@ -256,18 +525,35 @@ static int wgrad_launch(const WgradSrc& src, int n_images, float* dw, float* dbi
   float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * kCh * kCh : nullptr;
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, src, n_images,
                      static_cast<float*>(workspace), dbp);
-  static_assert(kDw4 % 256 == 0, "reduce grid");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(kDw4 / 256), dim3(256), 0, s, static_cast<const float4*>(workspace), shares,
-                     reinterpret_cast<float4*>(dw), dbp, dbias);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kDw4 + 63) / 64), dim3(64 * kRedGroups), 0, s, static_cast<const float4*>(workspace),
+                     shares, reinterpret_cast<float4*>(dw), dbp, dbias, kDw4, kCh);
   return mz::check_launch(who);
+}
+
+int64_t mz_conv_wgrad_workspace_bytes_for(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+  if (B <= 0) return 0;
+  if (H == kSide && W == kSide && Cin == kCh && Cout == kCh) return mz_conv_wgrad_workspace_bytes(B);
+  if (wg_matches<WgStem>(H, W, Cin, Cout)) return wg_workspace<WgStem>(B);
+  if (wg_matches<WgDown0>(H, W, Cin, Cout)) return wg_workspace<WgDown0>(B);
+  if (wg_matches<WgMid>(H, W, Cin, Cout)) return wg_workspace<WgMid>(B);
+  if (wg_matches<WgDown1>(H, W, Cin, Cout)) return wg_workspace<WgDown1>(B);
+  return 0;
 }
 
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream) {
   MZ_REQUIRE(grad_out && x && dw && workspace && B > 0, "mz_conv_wgrad_bf16: null tensor or empty batch");
-  MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
-             "mz_conv_wgrad_bf16: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin, Cout);
+  if (!(H == kSide && W == kSide && Cin == kCh && Cout == kCh)) {
+    MZ_REQUIRE(((uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "mz_conv_wgrad_bf16: dw and workspace must be 16-byte aligned");
+    hipStream_t s = mz::as_stream(stream);
+    if (wg_matches<WgStem>(H, W, Cin, Cout)) return wg_launch<WgStem>(grad_out, x, B, dw, dbias, workspace, workspace_bytes, s);
+    if (wg_matches<WgDown0>(H, W, Cin, Cout)) return wg_launch<WgDown0>(grad_out, x, B, dw, dbias, workspace, workspace_bytes, s);
+    if (wg_matches<WgMid>(H, W, Cin, Cout)) return wg_launch<WgMid>(grad_out, x, B, dw, dbias, workspace, workspace_bytes, s);
+    if (wg_matches<WgDown1>(H, W, Cin, Cout)) return wg_launch<WgDown1>(grad_out, x, B, dw, dbias, workspace, workspace_bytes, s);
+    return mz::fail(MZ_E_ARG, "mz_conv_wgrad_bf16: no kernel for a %dx%d input, %d->%d channels (the reference "
+                    "architecture's five layer shapes have one)", H, W, Cin, Cout);
+  }
   WgradSrc src{};
   src.gout[0] = static_cast<const __bf16*>(grad_out);
   src.x[0] = static_cast<const __bf16*>(x);

@@ -36,6 +36,43 @@ def test_weight_gradient_kernel_against_torch(N):
     assert err <= 2e-5 * scale + 1e-6, (err, scale)           # float32 accumulation of exact bf16 products
 
 
+OTHER_SHAPES = [(96, 96, 256, 2), (48, 256, 128, 2), (24, 128, 128, 1), (24, 128, 256, 2)]     # input side, Cin, Cout, stride
+
+
+@pytest.mark.parametrize("H,cin,cout,s", OTHER_SHAPES)
+@pytest.mark.parametrize("N", [1, 3, 37])
+def test_weight_gradient_of_the_other_layer_shapes_against_torch(H, cin, cout, s, N):
+    """The representation network's four other convolution shapes (model.py:165, :182): dW and the bias gradient
+    against torch's float64 gradient on the same bf16 operands; batch sizes that give a workgroup one band of one
+    image, several, and a ragged share of them."""
+    from muzero_amd import _lib
+    g = torch.Generator().manual_seed(N + H)
+    Ho = H // s
+    x = _bf16(torch.randn(N, H, H, cin, generator=g))
+    go = _bf16(torch.randn(N, Ho, Ho, cout, generator=g) * 0.1)
+    xd, gd = x.cuda(), go.cuda()
+    need = _lib.lib().mz_conv_wgrad_workspace_bytes_for(N, H, H, cin, cout)
+    assert need > 0
+    ws = torch.full((need // 4,), float("nan"), dtype=torch.float32, device="cuda")
+    dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device="cuda")
+    db = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda")
+    _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gd), _lib.ptr(xd), N, H, H, cin, cout, _lib.ptr(dw), _lib.ptr(db),
+              _lib.ptr(ws), need, _lib.current_stream())
+    db_ref = go.double().sum(dim=(0, 1, 2))
+    assert (db.double().cpu() - db_ref).abs().max().item() <= 1e-5 * db_ref.abs().max().item() + 1e-4
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double().cuda(), (cout, cin, 3, 3),
+                                      go.permute(0, 3, 1, 2).double().cuda(), stride=s, padding=1)
+    err = (dw.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 5e-5 * scale + 1e-5, (err, scale)           # float32 accumulation of exact bf16 products
+    with pytest.raises(_lib.MuZeroAmdError, match="workspace"):
+        _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gd), _lib.ptr(xd), N, H, H, cin, cout, _lib.ptr(dw), _lib.ptr(db),
+                  _lib.ptr(ws), need - 4, _lib.current_stream())
+    with pytest.raises(_lib.MuZeroAmdError, match="no kernel"):
+        _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gd), _lib.ptr(xd), N, H, H, cin + 32, cout, _lib.ptr(dw), _lib.ptr(db),
+                  _lib.ptr(ws), need, _lib.current_stream())
+
+
 def test_data_gradient_is_the_forward_kernel_on_transposed_weights():
     from muzero_amd import _lib, mfma
     g = torch.Generator().manual_seed(2)
