@@ -476,7 +476,20 @@ int64_t mz_conv_wgrad_workspace_bytes_for(int32_t B, int32_t H, int32_t W, int32
 int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H, int32_t W, int32_t Cin,
                        int32_t Cout, float* dw, float* dbias, void* workspace, int64_t workspace_bytes,
                        mz_stream_t stream);
-/* The same for one layer applied to several batches - the dynamics network's convolutions run once per unroll
+/* Data gradient of a stride-2 3x3 convolution (padding 1): dx bf16 NHWC [B][H][W][Cin] = sum over the taps (ky, kx)
+ * that reach the pixel and over co of grad_out[n][(iy+1-ky)/2][(ix+1-kx)/2][co] * w[co][ci][ky][kx], grad_out bf16
+ * NHWC [B][H/2][W/2][Cout], float32 accumulation (the backward pass of DownsampleBlock.conv, model.py:165, under
+ * train.py:303-308).  H, W: the layer's INPUT size.  Kernels exist for the reference architecture's two stride-2
+ * layers whose input needs a gradient: 48x48 256->128 and 24x24 128->256; other shapes return MZ_E_ARG.  wpk: the
+ * layer's weights (float [Cout][Cin][3][3]) packed by mz_weights_pack_dgrad_s2 into a caller-owned buffer of
+ * mz_packed_dgrad_s2_elems(Cout, Cin) bf16 elements (per parity class of (iy, ix), the taps that reach it, in
+ * MFMA fragment order). */
+int64_t mz_packed_dgrad_s2_elems(int32_t Cout, int32_t Cin);
+int mz_weights_pack_dgrad_s2(const float* w, int32_t Cout, int32_t Cin, void* out, mz_stream_t stream);
+int mz_conv_dgrad_s2_bf16(const void* grad_out, const void* wpk, void* dx, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                          int32_t Cout, mz_stream_t stream);
+
+/* mz_conv_wgrad_bf16 for one layer applied to several batches - the dynamics network's convolutions run once per unroll
  * step with the same weights (train.py:356-372), and the weight gradient of the update is the sum over the
  * steps: grad_out[i], x[i] (host arrays of n_segments <= 8 device pointers, B images each) are treated as one
  * batch of n_segments * B images, so the sum costs one pass and one reduction instead of one per step.

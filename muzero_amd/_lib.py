@@ -91,6 +91,9 @@ _SIGNATURES = {
     "mz_comm_destroy": (C.c_int, [_P]),
     "mz_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32]),
     "mz_conv_wgrad_workspace_bytes_for": (C.c_int64, [C.c_int32] * 5),
+    "mz_packed_dgrad_s2_elems": (C.c_int64, [C.c_int32, C.c_int32]),
+    "mz_weights_pack_dgrad_s2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mz_conv_dgrad_s2_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),
     "mz_conv_wgrad_bf16": (C.c_int, [_P, _P] + [C.c_int32] * 5 + [_P, _P, _P, C.c_int64, _P]),
     "mz_conv_wgrad_bf16_multi": (C.c_int, [_P, _P] + [C.c_int32] * 6 + [_P, _P, _P, C.c_int64, _P]),
     "mz_bn_workspace_bytes": (C.c_int64, [C.c_int32]),

@@ -11,9 +11,10 @@ Counterparts in the reference:
 
 Division of labour: the learner is the one place where gradients are needed.  It keeps the
 network as torch modules (same parameter names as the reference, BatchNorm in training mode
-as train.py:155 leaves it) and lets torch autograd differentiate the convolutions; the
-support cross-entropy (forward and gradient) and the n-step targets are HIP kernels
-(``mz_support_ce``, ``mz_nstep_targets``).  After an update ``Learner.state_dict()`` is
+as train.py:155 leaves it) under torch autograd; with precision "bf16" the 3x3 convolutions
+(forward, data gradient, weight gradient) and the BatchNorm + ReLU around them are this
+library's kernels, wrapped as autograd functions; the support cross-entropy (forward and
+gradient) and the n-step targets are HIP kernels (``mz_support_ce``, ``mz_nstep_targets``).  After an update ``Learner.state_dict()`` is
 broadcast (``muzero_amd.dist.broadcast_state_dict``) and loaded into the inference engine
 (``MuZeroNetwork.load_state_dict``), which folds BatchNorm for the search.
 """
@@ -33,14 +34,30 @@ from . import _lib, checkpoint
 _PACK_EPOCH = [0]     # bumped at the start of every unrolled forward pass (Learner.losses_from_tensors)
 
 
-class _PackedWeights:
-    """Fragment-packed bf16 copies of one convolution's float32 weight (forward form and the
-    transposed, mirrored form of the data gradient), repacked on the device when the parameter has
-    changed (optimizer steps bump its version counter)."""
+# The reference architecture's 3x3 layers (model.py:146-148, :165, :182), (cin, cout, stride) -> input side: the
+# shapes this library has forward, data-gradient and weight-gradient kernels for.
+_NATIVE_LAYERS = {(96, 256, 2): 96, (256, 128, 2): 48, (128, 128, 1): 24, (128, 256, 2): 24, (256, 256, 1): 12}
 
-    def __init__(self):
+
+class _PackedWeights:
+    """Fragment-packed bf16 copies of one convolution's float32 weight (forward form and the form its data
+    gradient reads: transposed and mirrored for a stride-1 layer, split by output parity for a stride-2 layer),
+    repacked on the device when the parameter has changed (optimizer steps bump its version counter)."""
+
+    def __init__(self, cin=256, cout=256, stride=1):
         self._slots = {}
         self.pending = None      # a list while the layer's weight gradients are deferred (see Conv3x3.defer_wgrad)
+        self.cin, self.cout, self.stride = cin, cout, stride
+        self._chunk = None
+
+    @property
+    def chunk(self) -> int:
+        """Input-channel chunk of the forward kernel's fragment order."""
+        if self._chunk is None:
+            from . import mfma
+            side = _NATIVE_LAYERS[(self.cin, self.cout, self.stride)]
+            self._chunk = mfma.kernel_info(side, side, self.cin, self.cout, self.stride)[0]
+        return self._chunk
 
     def key(self, weight: torch.Tensor):
         # while a HIP graph of the update is being recorded the packing must be part of it (a replay runs no
@@ -53,8 +70,9 @@ class _PackedWeights:
         from . import mfma
         slot = self._slots.get(transpose)
         if slot is None:
-            slot = self._slots[transpose] = (None, torch.empty(mfma.packed_elems(256, 256), dtype=torch.bfloat16,
-                                                               device=weight.device))
+            elems = (_lib.lib().mz_packed_dgrad_s2_elems(self.cout, self.cin) if transpose and self.stride == 2
+                     else mfma.packed_elems(self.cout, self.cin))
+            slot = self._slots[transpose] = (None, torch.empty(elems, dtype=torch.bfloat16, device=weight.device))
         return slot[1]
 
     def mark_current(self, weight: torch.Tensor, transpose: bool) -> None:
@@ -67,36 +85,41 @@ class _PackedWeights:
         slot = self._slots.get(transpose)
         if slot is None or slot[0] != key:
             buf = self.buffer(weight, transpose)
-            _lib.call("mz_weights_fold_pack", _lib.ptr(weight.detach()), None, None, None, None, None, 0.0, 256, 256, 256,
-                      0, 1 if transpose else 0, 0, _lib.ptr(buf), None, _lib.current_stream())
+            if transpose and self.stride == 2:
+                _lib.call("mz_weights_pack_dgrad_s2", _lib.ptr(weight.detach()), self.cout, self.cin, _lib.ptr(buf),
+                          _lib.current_stream())
+            else:
+                _lib.call("mz_weights_fold_pack", _lib.ptr(weight.detach()), None, None, None, None, None, 0.0, self.cout,
+                          self.cin, self.chunk, 0, 1 if transpose else 0, 0, _lib.ptr(buf), None, _lib.current_stream())
             self._slots[transpose] = (key, buf)
         return self._slots[transpose][1]
 
 
 class _Conv3x3Native(torch.autograd.Function):
-    """conv2d(x, w, b, stride 1, padding 1) for the 12x12, 256->256 layers on this library's kernels:
-    forward and data gradient = mz_conv3x3_bf16 (the latter on the transposed, mirrored weights), weight
-    gradient = mz_conv_wgrad_bf16.  x: bf16 [N, 256, 12, 12] in channels_last memory (= the kernels' NHWC)."""
+    """conv2d(x, w, b, stride, padding 1) for the layer shapes of _NATIVE_LAYERS on this library's kernels: forward
+    = mz_conv3x3_bf16; data gradient = the same kernel on the transposed, mirrored weights (stride 1) or
+    mz_conv_dgrad_s2_bf16 (stride 2); weight and bias gradient = mz_conv_wgrad_bf16.
+    x: bf16 [N, Cin, H, W] in channels_last memory (= the kernels' NHWC)."""
 
     @staticmethod
-    def _conv(x_nhwc, wpk, bias):
-        n = x_nhwc.shape[0]
-        out = torch.empty_like(x_nhwc)
+    def _conv(x_nhwc, wpk, bias, cout, stride):
+        n, h, w, cin = x_nhwc.shape
+        out = torch.empty(n, h // stride, w // stride, cout, dtype=torch.bfloat16, device=x_nhwc.device)
         _lib.call("mz_conv3x3_bf16", _lib.ptr(x_nhwc), None, 0, _lib.ptr(wpk), _lib.ptr(bias), None, _lib.ptr(out), None,
-                  None, None, n, 12, 12, 256, 256, 1, 0, _lib.current_stream())
+                  None, None, n, h, w, cin, cout, stride, 0, _lib.current_stream())
         return out
 
     @staticmethod
     def forward(ctx, x, weight, bias, packed, want_stats=False):
-        """want_stats: also return double [N, 2, 256], per image the sum and the sum of squares of the outputs -
-        the column sums a following training-mode BatchNorm would otherwise get from a pass of its own."""
+        """want_stats (12x12 layers): also return double [N, 2, 256], per image the sum and the sum of squares of
+        the outputs - the column sums a following training-mode BatchNorm would otherwise get from a pass of its own."""
         xh = x.permute(0, 2, 3, 1)
         if not xh.is_contiguous() or x.dtype != torch.bfloat16:
             raise ValueError("native convolution: bf16 channels_last input expected")
         ctx.save_for_backward(x, weight)
         ctx.packed = packed
         if not want_stats:
-            out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float())
+            out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float(), packed.cout, packed.stride)
             return out.permute(0, 3, 1, 2)
         n = xh.shape[0]
         out = torch.empty_like(xh)
@@ -109,38 +132,56 @@ class _Conv3x3Native(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad, *unused):
         x, weight = ctx.saved_tensors
+        pk = ctx.packed
         g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         gh, xh = g.permute(0, 2, 3, 1), x.permute(0, 2, 3, 1)
-        n = x.shape[0]
+        n, h, w, cin = xh.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            zero = _zero_bias(x.device)
-            dx = _Conv3x3Native._conv(gh, ctx.packed.get(weight, True), zero).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1] and ctx.packed.pending is not None:
-            ctx.packed.pending.append((gh, xh))       # summed over the unroll steps by Conv3x3.flush_wgrad
+            if pk.stride == 1:
+                dx = _Conv3x3Native._conv(gh, pk.get(weight, True), _zero_bias(x.device, cin), cin, 1).permute(0, 3, 1, 2)
+            elif cin == 96:      # the first layer: in the network its input is the observation and needs no gradient
+                dx = torch.ops.aten.convolution_backward(g, x, weight.detach().to(torch.bfloat16), None, [2, 2], [1, 1],
+                                                         [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            else:
+                dxh = torch.empty_like(xh)
+                _lib.call("mz_conv_dgrad_s2_bf16", _lib.ptr(gh), _lib.ptr(pk.get(weight, True)), _lib.ptr(dxh), n, h, w,
+                          cin, pk.cout, _lib.current_stream())
+                dx = dxh.permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1] and pk.pending is not None:
+            pk.pending.append((gh, xh))       # summed over the unroll steps by Conv3x3.flush_wgrad
         elif ctx.needs_input_grad[1]:
-            need = _lib.lib().mz_conv_wgrad_workspace_bytes(n)
+            need = _lib.lib().mz_conv_wgrad_workspace_bytes_for(n, h, w, cin, pk.cout)
             ws = _wgrad_workspace(need, x.device)
-            dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=x.device)
+            dw = torch.empty(pk.cout, cin, 3, 3, dtype=torch.float32, device=x.device)
             if ctx.needs_input_grad[2]:      # the bias gradient comes out of the same pass over grad
-                db = torch.empty(256, dtype=torch.float32, device=x.device)
-            _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gh), _lib.ptr(xh), n, 12, 12, 256, 256, _lib.ptr(dw), _lib.ptr(db),
+                db = torch.empty(pk.cout, dtype=torch.float32, device=x.device)
+            _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gh), _lib.ptr(xh), n, h, w, cin, pk.cout, _lib.ptr(dw), _lib.ptr(db),
                       _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
         elif ctx.needs_input_grad[2]:
             db = g.sum(dim=(0, 2, 3), dtype=torch.float32)
         return dx, dw, db, None, None
 
 
+def pack_dgrad_s2(weight: torch.Tensor) -> torch.Tensor:
+    """A stride-2 layer's float32 device weight [Cout][Cin][3][3] in the form mz_conv_dgrad_s2_bf16 reads."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    out = torch.empty(_lib.lib().mz_packed_dgrad_s2_elems(cout, cin), dtype=torch.bfloat16, device=weight.device)
+    _lib.call("mz_weights_pack_dgrad_s2", _lib.ptr(weight.detach().float().contiguous()), cout, cin, _lib.ptr(out),
+              _lib.current_stream())
+    return out
+
+
 _WGRAD_WS: Dict[tuple, torch.Tensor] = {}
 _ZERO_BIAS: Dict[tuple, torch.Tensor] = {}
 
 
-def _zero_bias(device) -> torch.Tensor:
-    """The all-zero bias of a data-gradient convolution (one per device, never written)."""
-    key = (device.type, device.index)
+def _zero_bias(device, channels: int = 256) -> torch.Tensor:
+    """The all-zero bias of a data-gradient convolution (one per device and width, never written)."""
+    key = (device.type, device.index, channels)
     t = _ZERO_BIAS.get(key)
     if t is None:
-        t = _ZERO_BIAS[key] = torch.zeros(256, dtype=torch.float32, device=device)
+        t = _ZERO_BIAS[key] = torch.zeros(channels, dtype=torch.float32, device=device)
     return t
 
 
@@ -155,15 +196,16 @@ def _wgrad_workspace(nbytes: int, device) -> torch.Tensor:
 
 
 class Conv3x3(nn.Conv2d):
-    """nn.Conv2d(c_in, c_out, 3, stride, 1) whose 12x12, 256->256 instances run on this library's
-    kernels (forward, data gradient, weight gradient) when the learner computes in bf16; every other
-    shape, the CPU and the float32 precision use torch's convolution.  Parameter names are nn.Conv2d's."""
+    """nn.Conv2d(c_in, c_out, 3, stride, 1) whose instances with one of the reference architecture's layer shapes
+    (_NATIVE_LAYERS) run on this library's kernels (forward, data gradient, weight gradient) when the learner
+    computes in bf16; every other shape, the CPU and the float32 precision use torch's convolution.  Parameter
+    names are nn.Conv2d's."""
 
     native = True        # Learner(native_convs=False) clears this on its modules
 
     def __init__(self, cin, cout, stride=1):
         super().__init__(cin, cout, 3, stride, 1)
-        self._packed = _PackedWeights()
+        self._packed = _PackedWeights(cin, cout, stride)
 
     def defer_wgrad(self, on: bool = True) -> None:
         """A layer applied at several unroll steps (the dynamics network's): its backward passes only record
@@ -196,8 +238,13 @@ class Conv3x3(nn.Conv2d):
                     p.grad = g if p.grad is None else p.grad + g
 
     def runs_native(self, x) -> bool:
-        return (self.native and x.is_cuda and torch.is_autocast_enabled() and self.stride == (1, 1)
-                and tuple(self.weight.shape) == (256, 256, 3, 3) and tuple(x.shape[1:]) == (256, 12, 12))
+        side = _NATIVE_LAYERS.get((self.in_channels, self.out_channels, self.stride[0]))
+        return (self.native and x.is_cuda and torch.is_autocast_enabled() and side is not None
+                and tuple(x.shape[1:]) == (self.in_channels, side, side))
+
+    def has_stats(self, x) -> bool:
+        """Whether the forward kernel of this layer can hand a following BatchNorm its column sums."""
+        return self.runs_native(x) and (self.in_channels, self.out_channels, self.stride[0]) == (256, 256, 1)
 
     def forward(self, x, want_stats: bool = False):
         """want_stats (native path only): returns (y, per-image column sums of y), see _Conv3x3Native.forward."""
@@ -293,7 +340,7 @@ def _bn_native(bn: nn.BatchNorm2d, x) -> bool:
 def conv_bn_act(conv: "Conv3x3", bn: nn.BatchNorm2d, x, residual=None):
     """relu(bn(conv(x)) [+ residual]): where both run on this library's kernels the convolution hands the
     BatchNorm its column sums, and the BatchNorm's own statistics pass over the activations falls away."""
-    if conv.runs_native(x) and getattr(bn, "native", False) and bn.training and bn.track_running_stats \
+    if conv.has_stats(x) and getattr(bn, "native", False) and bn.training and bn.track_running_stats \
             and bn.momentum is not None:
         y, stats = conv(x, want_stats=True)
         return bn_act(bn, y, residual, stats=stats)
@@ -896,8 +943,8 @@ class Learner:
                  native_convs: bool = True):
         """precision "fp32" is the reference's arithmetic (parity tests run in it); "bf16" runs the
         convolutions and linear layers under bfloat16 autocast with float32 master weights,
-        BatchNorm statistics and losses - and, with native_convs, the 12x12 256->256 convolutions
-        (forward, data gradient, weight gradient) on this library's MFMA kernels instead of MIOpen.
+        BatchNorm statistics and losses - and, with native_convs, the 3x3 convolutions (forward, data
+        gradient, weight gradient) on this library's MFMA kernels instead of MIOpen.
         autotune: see below."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -1105,19 +1152,25 @@ class Learner:
             return
         convs = getattr(self, "_native_conv_list", None)
         if convs is None:
-            convs = self._native_conv_list = [m for m in self.network.modules() if isinstance(m, Conv3x3)
-                                              and m.stride == (1, 1) and tuple(m.weight.shape) == (256, 256, 3, 3)]
+            convs = self._native_conv_list = [m for m in self.network.modules() if isinstance(m, Conv3x3) and
+                                              (m.in_channels, m.out_channels, m.stride[0]) in _NATIVE_LAYERS]
         todo = [(m, t) for m in convs for t in (False, True)
-                if m._packed._slots.get(t) is None or m._packed._slots[t][0] != m._packed.key(m.weight)]
-        if not todo:
-            return
-        n = len(todo)
-        w = (C.c_void_p * n)(*[m.weight.data_ptr() for m, _ in todo])
-        out = (C.c_void_p * n)(*[m._packed.buffer(m.weight, t).data_ptr() for m, t in todo])
-        tr = (C.c_int32 * n)(*[1 if t else 0 for _, t in todo])
-        _lib.call("mz_weights_pack_many", w, out, tr, n, 256, 256, 256, _lib.current_stream())
+                if not (t and m is self.network.representation.conv1)       # its input needs no gradient
+                and (m._packed._slots.get(t) is None or m._packed._slots[t][0] != m._packed.key(m.weight))]
+        groups: Dict[tuple, list] = {}
         for m, t in todo:
-            m._packed.mark_current(m.weight, t)
+            if t and m.stride[0] == 2:            # the parity-split form has a packing of its own
+                m._packed.get(m.weight, True)
+            else:
+                groups.setdefault((m.out_channels, m.in_channels, m._packed.chunk), []).append((m, t))
+        for (cout, cin, chunk), items in groups.items():
+            n = len(items)
+            w = (C.c_void_p * n)(*[m.weight.data_ptr() for m, _ in items])
+            out = (C.c_void_p * n)(*[m._packed.buffer(m.weight, t).data_ptr() for m, t in items])
+            tr = (C.c_int32 * n)(*[1 if t else 0 for _, t in items])
+            _lib.call("mz_weights_pack_many", w, out, tr, n, cout, cin, chunk, _lib.current_stream())
+            for m, t in items:
+                m._packed.mark_current(m.weight, t)
 
     def _backward(self, loss) -> None:
         """loss.backward() with the weight gradients of the dynamics network's native convolutions - applied

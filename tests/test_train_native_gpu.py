@@ -73,6 +73,30 @@ def test_weight_gradient_of_the_other_layer_shapes_against_torch(H, cin, cout, s
                   _lib.ptr(ws), need, _lib.current_stream())
 
 
+@pytest.mark.parametrize("H,cin,cout", [(48, 256, 128), (24, 128, 256)])
+@pytest.mark.parametrize("N", [1, 5])
+def test_stride2_data_gradient_against_torch(H, cin, cout, N):
+    """mz_conv_dgrad_s2_bf16 (the two stride-2 layers whose input needs a gradient, model.py:165) against torch's
+    float64 conv2d_input on the same bf16 operands: the output is rounded to bf16, nothing else."""
+    from muzero_amd import _lib
+    from muzero_amd.learner import pack_dgrad_s2
+    g = torch.Generator().manual_seed(N + H)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    go = _bf16(torch.randn(N, H // 2, H // 2, cout, generator=g))
+    wpk = pack_dgrad_s2(w.cuda())
+    gd = go.cuda()
+    dx = torch.full((N, H, H, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.call("mz_conv_dgrad_s2_bf16", _lib.ptr(gd), _lib.ptr(wpk), _lib.ptr(dx), N, H, H, cin, cout, _lib.current_stream())
+    ref = torch.nn.grad.conv2d_input((N, cin, H, H), _bf16(w).double().cuda(), go.permute(0, 3, 1, 2).double().cuda(),
+                                     stride=2, padding=1).permute(0, 2, 3, 1)
+    assert not torch.isnan(dx.float()).any()
+    err = (dx.double() - ref).abs()
+    assert bool((err <= 4e-3 * ref.abs() + 1e-3 * ref.abs().max()).all()), float(err.max())
+    with pytest.raises(_lib.MuZeroAmdError, match="no kernel"):
+        _lib.call("mz_conv_dgrad_s2_bf16", _lib.ptr(gd), _lib.ptr(wpk), _lib.ptr(dx), N, H, H, cin, cout + 16,
+                  _lib.current_stream())
+
+
 def test_data_gradient_is_the_forward_kernel_on_transposed_weights():
     from muzero_amd import _lib, mfma
     g = torch.Generator().manual_seed(2)
@@ -94,18 +118,23 @@ def test_data_gradient_is_the_forward_kernel_on_transposed_weights():
     assert err <= 6e-3 * ref.abs().max().item()               # the output is rounded to bf16 (2^-8 relative)
 
 
-def test_native_conv_module_matches_torch_autograd():
+@pytest.mark.parametrize("H,cin,cout,s", OTHER_SHAPES + [(12, 256, 256, 1)])
+def test_native_conv_module_matches_torch_autograd(H, cin, cout, s):
+    """Conv3x3 on this library's kernels (forward, data gradient, weight and bias gradient) against the same module
+    on torch's bf16 convolution, for each of the reference architecture's layer shapes."""
     from muzero_amd.learner import Conv3x3
     torch.manual_seed(0)
-    a, b = Conv3x3(256, 256).cuda(), Conv3x3(256, 256).cuda()
+    a, b = Conv3x3(cin, cout, s).cuda(), Conv3x3(cin, cout, s).cuda()
     b.load_state_dict(a.state_dict())
     b.native = False
-    x = torch.randn(16, 256, 12, 12, device="cuda")
-    up = torch.randn(16, 256, 12, 12, device="cuda")
+    x = torch.randn(6, cin, H, H, device="cuda")
+    up = torch.randn(6, cout, H // s, H // s, device="cuda")
+    assert a.runs_native(x.to(torch.bfloat16)) is False            # outside autocast: torch's convolution
     outs = []
     for m in (a, b):
         xi = x.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert m.runs_native(xi) == (m is a)
             y = m(xi)
         assert y.dtype == torch.bfloat16
         (y.float() * up).sum().backward()
