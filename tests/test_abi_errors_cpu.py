@@ -34,7 +34,9 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_weights_fold_pack", one, None, None, None, None, None, 1e-5, 250, 96, 96, 0, 0, 0, one, None, None,
            match="fragments")
     _fails("mz_pack_linear", one, None, 601, 250, 1, one, None, None, match="multiple")
-    _fails("mz_conv_wgrad_bf16", one, one, 4, 24, 24, 128, 128, one, None, one, 1 << 30, None, match="12x12")
+    _fails("mz_conv_wgrad_bf16", one, one, 4, 20, 20, 128, 128, one, None, one, 1 << 30, None, match="no kernel")
+    _fails("mz_conv_wgrad_bf16", one, one, 4, 24, 24, 128, 128, one, None, one, 16, None, match="workspace")
+    _fails("mz_conv_wgrad_bf16", one, one, 4000, 96, 96, 96, 256, one, None, one, 1 << 40, None, match="4 GiB")
     _fails("mz_conv_wgrad_bf16", one, one, 4, 12, 12, 256, 256, one, None, one, 16, None, match="workspace")
     two = (C.c_void_p * 2)(16, 16)
     _fails("mz_conv_wgrad_bf16_multi", two, two, 9, 4, 12, 12, 256, 256, one, None, one, 1 << 30, None, match="n_segments")
@@ -72,6 +74,10 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_weights_fold_pack", one, None, None, None, None, None, 1e-5, 256, 256, 256, 4, 0, 0, one, None, None,
            match="mode")
     _fails("mz_pack_linear", one, None, 601, 256, 3, one, None, None, match="format")
+    # the stride-2 data gradient and its packing
+    _fails("mz_conv_dgrad_s2_bf16", None, one, one, 4, 48, 48, 256, 128, None, match="null tensor")
+    _fails("mz_conv_dgrad_s2_bf16", one, one, one, 4, 96, 96, 96, 256, None, match="no kernel")
+    _fails("mz_weights_pack_dgrad_s2", one, 100, 256, one, None, match="multiple of")
 
 
 def test_size_queries():
@@ -82,3 +88,5 @@ def test_size_queries():
     assert lib.mz_replay_static_max_positions() == 16 << 20
     assert lib.mz_bn_workspace_bytes(256) == 256 * 2 * 256 * 8 + 3 * 256 * 4
     assert lib.mz_conv_wgrad_workspace_bytes(0) == 0
+    assert lib.mz_conv_wgrad_workspace_bytes_for(4, 20, 20, 128, 128) == 0          # a shape without a kernel
+    assert lib.mz_packed_dgrad_s2_elems(128, 256) == 128 * 256 * 9 + 4 * 16 * 512
