@@ -121,33 +121,38 @@ def test_data_gradient_is_the_forward_kernel_on_transposed_weights():
 @pytest.mark.parametrize("H,cin,cout,s", OTHER_SHAPES + [(12, 256, 256, 1)])
 def test_native_conv_module_matches_torch_autograd(H, cin, cout, s):
     """Conv3x3 on this library's kernels (forward, data gradient, weight and bias gradient) against the same module
-    on torch's bf16 convolution, for each of the reference architecture's layer shapes."""
+    on torch's float32 convolution, for each of the reference architecture's layer shapes.  Input, weights and
+    the incoming gradient hold bf16-representable values, so the float32 module computes what the kernels compute
+    up to the bf16 rounding of their outputs (y, dx) and float32 summation order (dW, db)."""
     from muzero_amd.learner import Conv3x3
     torch.manual_seed(0)
     a, b = Conv3x3(cin, cout, s).cuda(), Conv3x3(cin, cout, s).cuda()
+    with torch.no_grad():
+        a.weight.copy_(_bf16(a.weight).float())
     b.load_state_dict(a.state_dict())
     b.native = False
-    x = torch.randn(6, cin, H, H, device="cuda")
-    up = torch.randn(6, cout, H // s, H // s, device="cuda")
+    x = _bf16(torch.randn(6, cin, H, H, device="cuda")).float()
+    up = _bf16(torch.randn(6, cout, H // s, H // s, device="cuda")).float()
     assert a.runs_native(x.to(torch.bfloat16)) is False            # outside autocast: torch's convolution
     outs = []
     for m in (a, b):
         xi = x.clone().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=m is a):
             assert m.runs_native(xi) == (m is a)
             y = m(xi)
-        assert y.dtype == torch.bfloat16
+        assert y.dtype == (torch.bfloat16 if m is a else torch.float32)
         (y.float() * up).sum().backward()
         outs.append((y.float(), xi.grad, m.weight.grad, m.bias.grad))
-    for (got, want, tol) in zip(outs[0], outs[1], (2e-2, 2e-2, 5e-3, 5e-3)):
+    for (got, want, tol) in zip(outs[0], outs[1], (5e-3, 5e-3, 1e-4, 1e-4)):
         assert got.shape == want.shape
         assert (got - want).abs().max().item() <= tol * want.abs().max().item()
     # a changed weight is repacked: the cached fragments follow the parameter's version counter
     with torch.no_grad():
         a.weight.mul_(2.0); b.weight.mul_(2.0)
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        ya, yb = a(x), b(x)
-    assert (ya.float() - yb.float()).abs().max().item() <= 2e-2 * yb.float().abs().max().item()
+        ya = a(x)
+    yb = b(x)
+    assert (ya.float() - yb).abs().max().item() <= 5e-3 * yb.abs().max().item()
 
 
 def test_full_size_update_native_against_torch_convolutions():
