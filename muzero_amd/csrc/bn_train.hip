@@ -44,29 +44,57 @@ __global__ __launch_bounds__(kStatsThreads) void bn_colsum_kernel(const unsigned
 #pragma unroll
     for (int j = 0; j < 8; ++j) { mu[j] = mean[cg * 8 + j]; is[j] = invstd[cg * 8 + j]; }
   }
+  auto accumulate = [&](const u16x8& xv, const u16x8& gv, const u16x8& yv) __attribute__((always_inline)) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double v = (double)bf16_to_f32(xv[j]);
+        s0[j] += v;
+        s1[j] += v * v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float g = bf16_to_f32(gv[j]);
+        if (relu && !(bf16_to_f32(yv[j]) > 0.f)) g = 0.f;
+        const float xh = (bf16_to_f32(xv[j]) - mu[j]) * is[j];
+        s0[j] += (double)g;
+        s1[j] += (double)g * (double)xh;
+      }
+    }
+  };
   if (rl < lanes) {
-    for (long r = (long)blockIdx.x * lanes + rl; r < rows; r += (long)gridDim.x * lanes) {
-      const u16x8 xv = *reinterpret_cast<const u16x8*>(x + r * C + cg * 8);
-      if (MODE == 0) {
+    // three rows per trip: their loads are in flight together (a thread walks ~9 rows at the training batch, and a
+    // round trip to HBM per row was most of the kernel's time)
+    const long step = (long)gridDim.x * lanes;
+    long r = (long)blockIdx.x * lanes + rl;
+    for (; r + 2 * step < rows; r += 3 * step) {
+      u16x8 xv[3], gv[3], yv[3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const double v = (double)bf16_to_f32(xv[j]);
-          s0[j] += v;
-          s1[j] += v * v;
-        }
-      } else {
-        const u16x8 gv = *reinterpret_cast<const u16x8*>(dy + r * C + cg * 8);
-        u16x8 yv = gv;
-        if (relu) yv = *reinterpret_cast<const u16x8*>(y + r * C + cg * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float g = bf16_to_f32(gv[j]);
-          if (relu && !(bf16_to_f32(yv[j]) > 0.f)) g = 0.f;
-          const float xh = (bf16_to_f32(xv[j]) - mu[j]) * is[j];
-          s0[j] += (double)g;
-          s1[j] += (double)g * (double)xh;
+      for (int k = 0; k < 3; ++k) {
+        const long o = (r + k * step) * C + cg * 8;
+        xv[k] = *reinterpret_cast<const u16x8*>(x + o);
+        if (MODE == 1) {
+          gv[k] = *reinterpret_cast<const u16x8*>(dy + o);
+          yv[k] = gv[k];
         }
       }
+      if (MODE == 1 && relu) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) yv[k] = *reinterpret_cast<const u16x8*>(y + (r + k * step) * C + cg * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) accumulate(xv[k], gv[k], yv[k]);
+    }
+    for (; r < rows; r += step) {
+      const u16x8 xv = *reinterpret_cast<const u16x8*>(x + r * C + cg * 8);
+      u16x8 gv = xv, yv = xv;
+      if (MODE == 1) {
+        gv = *reinterpret_cast<const u16x8*>(dy + r * C + cg * 8);
+        yv = gv;
+        if (relu) yv = *reinterpret_cast<const u16x8*>(y + r * C + cg * 8);
+      }
+      accumulate(xv, gv, yv);
     }
   }
   // combine the row lanes of this workgroup: [lane][2][C] doubles in LDS

@@ -118,6 +118,7 @@ class _Conv3x3Native(torch.autograd.Function):
             raise ValueError("native convolution: bf16 channels_last input expected")
         ctx.save_for_backward(x, weight)
         ctx.packed = packed
+        ctx.set_materialize_grads(False)     # no zero-filled "gradient" of the statistics output per backward call
         if not want_stats:
             out = _Conv3x3Native._conv(xh, packed.get(weight, False), bias.detach().float(), packed.cout, packed.stride)
             return out.permute(0, 3, 1, 2)
@@ -131,6 +132,8 @@ class _Conv3x3Native(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad, *unused):
+        if grad is None:
+            return None, None, None, None, None
         x, weight = ctx.saved_tensors
         pk = ctx.packed
         g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

@@ -312,14 +312,16 @@ def test_eager_passes_between_graph_replays_see_the_current_weights():
     assert seen[2] < seen[1] < seen[0], seen                   # and the loss moves between the eager passes
 
 
+@pytest.mark.parametrize("N", [24, 128])
 @pytest.mark.parametrize("with_residual", [False, True])
-def test_fused_batchnorm_relu_against_torch(with_residual):
+def test_fused_batchnorm_relu_against_torch(with_residual, N):
     """mz_bn_relu_train_fwd / _bwd through bn_act against torch's BatchNorm2d + add + ReLU in float32 on the same
-    bf16 inputs: output, input / residual / affine gradients, running statistics, batch counter."""
+    bf16 inputs: output, input / residual / affine gradients, running statistics, batch counter.  (At N = 128 a
+    thread of the column-sum kernels walks nine rows: three trips of three.)"""
     import torch.nn as nn
     from muzero_amd.learner import bn_act
     torch.manual_seed(3)
-    N, C = 24, 256
+    C = 256
     a, b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
     with torch.no_grad():
         a.weight.uniform_(0.5, 1.5); a.bias.normal_(0, 0.2)
