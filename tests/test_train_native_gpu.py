@@ -73,8 +73,35 @@ def test_weight_gradient_of_the_other_layer_shapes_against_torch(H, cin, cout, s
                   _lib.ptr(ws), need, _lib.current_stream())
 
 
+def test_weight_gradient_addresses_past_two_gigabytes():
+    """The first layer at 1300 images: x is 2.3 GB, so the kernel's 32-bit byte offsets pass 2^31.  Only the last
+    seven images are non-zero; the result must equal the gradient of those seven alone (same products, another
+    split into shares: float32 summation order only)."""
+    from muzero_amd import _lib
+    H, cin, cout, N, live = 96, 96, 256, 1300, 7
+    g = torch.Generator().manual_seed(5)
+    x = torch.zeros(N, H, H, cin, dtype=torch.bfloat16, device="cuda")
+    go = torch.zeros(N, H // 2, H // 2, cout, dtype=torch.bfloat16, device="cuda")
+    x[N - live:] = _bf16(torch.randn(live, H, H, cin, generator=g)).cuda()
+    go[N - live:] = _bf16(torch.randn(live, H // 2, H // 2, cout, generator=g) * 0.1).cuda()
+    out = []
+    for xs, gs, n in ((x, go, N), (x[N - live:].contiguous(), go[N - live:].contiguous(), live)):
+        need = _lib.lib().mz_conv_wgrad_workspace_bytes_for(n, H, H, cin, cout)
+        ws = torch.empty(need // 4, dtype=torch.float32, device="cuda")
+        dw = torch.full((cout, cin, 3, 3), float("nan"), dtype=torch.float32, device="cuda")
+        db = torch.full((cout,), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.call("mz_conv_wgrad_bf16", _lib.ptr(gs), _lib.ptr(xs), n, H, H, cin, cout, _lib.ptr(dw), _lib.ptr(db),
+                  _lib.ptr(ws), need, _lib.current_stream())
+        out.append((dw, db))
+    (dw_a, db_a), (dw_b, db_b) = out
+    scale = dw_b.abs().max().item()
+    assert scale > 1.0
+    assert (dw_a - dw_b).abs().max().item() <= 2e-5 * scale
+    assert (db_a - db_b).abs().max().item() <= 2e-5 * db_b.abs().max().item() + 1e-4
+
+
 @pytest.mark.parametrize("H,cin,cout", [(48, 256, 128), (24, 128, 256)])
-@pytest.mark.parametrize("N", [1, 5])
+@pytest.mark.parametrize("N", [1, 5, 130])
 def test_stride2_data_gradient_against_torch(H, cin, cout, N):
     """mz_conv_dgrad_s2_bf16 (the two stride-2 layers whose input needs a gradient, model.py:165) against torch's
     float64 conv2d_input on the same bf16 operands: the output is rounded to bf16, nothing else."""
