@@ -458,6 +458,18 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
                      const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
                      double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream);
 
+/* The dynamics network's "hidden + conv_action(one-hot action planes)" (model.py:231-236) in the training step
+ * (train.py:356-372), forward and the gradient of its parameters.  h, out, dy: bf16 NHWC [B][HW][C]; table: float
+ * [A][C] = conv_action's weight column of each action + its bias (mz_action_vectors' layout); actions int32 [B],
+ * 0 <= actions[b] < A guaranteed by the caller.  Forward: out = bf16(h + table[actions[b]]) on every pixel of
+ * image b.  Gradient: dtable float [A][C] = sum over the images with that action and over their pixels of dy (the
+ * gradient with respect to h is dy itself); image_sums: caller-owned float [B][C] scratch.  No atomics: the same
+ * bits on every run. */
+int mz_add_action_vector_bf16(const void* h, const float* table, const int32_t* actions, void* out, int32_t B,
+                              int32_t HW, int32_t C, mz_stream_t stream);
+int mz_action_vector_grad_bf16(const void* dy, const int32_t* actions, int32_t B, int32_t HW, int32_t C, int32_t A,
+                               float* image_sums, float* dtable, mz_stream_t stream);
+
 /* Weight gradient of a 3x3 convolution (padding 1) for the unrolled training step (compute_losses' backward
  * pass, train.py:303-308): dw float [Cout][Cin][3][3] = sum over images and output pixels of
  * grad_out[n][y][x][co] * x[n][s*y+ky-1][s*x+kx-1][ci]; grad_out (bf16 NHWC [B][H/s][W/s][Cout]) and x (bf16 NHWC

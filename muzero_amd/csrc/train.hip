@@ -105,9 +105,103 @@ __global__ void nstep_targets_kernel(const double* __restrict__ rewards, const d
   }
 }
 
+// ---- "hidden + conv1x1(one-hot action planes)" of the dynamics network (model.py:231-236) in the training step:
+// on every pixel of image b the planes contribute table[actions[b]][c] (table = conv_action's weight column +
+// bias).  bf16 NHWC activations, float32 table; the sum is rounded to bf16 once.
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                               // nearest even
+  return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void add_action_vector_kernel(const unsigned short* __restrict__ h,
+                                                               const float* __restrict__ table,
+                                                               const int* __restrict__ actions, long units, int per_image,
+                                                               int C, unsigned short* __restrict__ out) {
+  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
+    const int b = (int)(u / per_image), c8 = (int)(u % (C / 8));
+    const float* v = table + (long)actions[b] * C + c8 * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(v), v1 = *reinterpret_cast<const float4*>(v + 4);
+    const u16x8 x = *reinterpret_cast<const u16x8*>(h + u * 8);
+    u16x8 y;
+    y[0] = f32_to_bf16_bits(bf16_bits_to_f32(x[0]) + v0.x); y[1] = f32_to_bf16_bits(bf16_bits_to_f32(x[1]) + v0.y);
+    y[2] = f32_to_bf16_bits(bf16_bits_to_f32(x[2]) + v0.z); y[3] = f32_to_bf16_bits(bf16_bits_to_f32(x[3]) + v0.w);
+    y[4] = f32_to_bf16_bits(bf16_bits_to_f32(x[4]) + v1.x); y[5] = f32_to_bf16_bits(bf16_bits_to_f32(x[5]) + v1.y);
+    y[6] = f32_to_bf16_bits(bf16_bits_to_f32(x[6]) + v1.z); y[7] = f32_to_bf16_bits(bf16_bits_to_f32(x[7]) + v1.w);
+    *reinterpret_cast<u16x8*>(out + u * 8) = y;
+  }
+}
+
+// Its gradient with respect to the table: dtable[a][c] = sum over the images b with actions[b] == a and over
+// their pixels of dy[b][pixel][c].  Two launches: per-image pixel sums (one workgroup per image: thread = channel
+// group x row lane, lanes combined through LDS), then per (a, c) the images in index order - no atomics, the
+// same bits every time.
+__global__ __launch_bounds__(256) void pixel_sum_kernel(const unsigned short* __restrict__ dy, int HW, int C,
+                                                       float* __restrict__ sums) {
+  __shared__ float red[256 * 8];
+  const int groups = C / 8, lanes = 256 / groups;
+  const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+  const unsigned short* img = dy + (long)blockIdx.x * HW * C;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes)
+    for (int r = rl; r < HW; r += lanes) {
+      const u16x8 v = *reinterpret_cast<const u16x8*>(img + (long)r * C + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += bf16_bits_to_f32(v[j]);
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[(rl * groups + cg) * 8 + j] = rl < lanes ? s[j] : 0.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * C + c];
+    sums[(long)blockIdx.x * C + c] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void action_group_sum_kernel(const float* __restrict__ sums,
+                                                              const int* __restrict__ actions, int B, int C, int A,
+                                                              float* __restrict__ dtable) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A * C) return;
+  const int a = i / C, c = i - a * C;
+  float t = 0.f;
+  for (int b = 0; b < B; ++b)
+    if (actions[b] == a) t += sums[(long)b * C + c];
+  dtable[i] = t;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mz_add_action_vector_bf16(const void* h, const float* table, const int32_t* actions, void* out, int32_t B,
+                              int32_t HW, int32_t C, mz_stream_t stream) {
+  MZ_REQUIRE(h && table && actions && out && B > 0 && HW > 0, "mz_add_action_vector_bf16: null tensor or empty batch");
+  MZ_REQUIRE(C >= 8 && C % 8 == 0, "mz_add_action_vector_bf16: C = %d must be a multiple of 8", C);
+  const long units = (long)B * HW * (C / 8);
+  const long want = (units + 255) / 256, cap = 8L * mz::compute_units();
+  hipLaunchKernelGGL(add_action_vector_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0,
+                     mz::as_stream(stream), static_cast<const unsigned short*>(h), table, actions, units, HW * (C / 8), C,
+                     static_cast<unsigned short*>(out));
+  return mz::check_launch("mz_add_action_vector_bf16");
+}
+
+int mz_action_vector_grad_bf16(const void* dy, const int32_t* actions, int32_t B, int32_t HW, int32_t C, int32_t A,
+                               float* image_sums, float* dtable, mz_stream_t stream) {
+  MZ_REQUIRE(dy && actions && image_sums && dtable && B > 0 && HW > 0 && A > 0,
+             "mz_action_vector_grad_bf16: null tensor or empty batch");
+  MZ_REQUIRE(C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0,
+             "mz_action_vector_grad_bf16: C = %d must be 8 times a power of two, at most 2048", C);
+  hipStream_t s = mz::as_stream(stream);
+  hipLaunchKernelGGL(pixel_sum_kernel, dim3(B), dim3(256), 0, s, static_cast<const unsigned short*>(dy), HW, C, image_sums);
+  hipLaunchKernelGGL(action_group_sum_kernel, dim3((A * C + 255) / 256), dim3(256), 0, s, image_sums, actions, B, C, A,
+                     dtable);
+  return mz::check_launch("mz_action_vector_grad_bf16");
+}
 
 int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,
                   mz_stream_t stream) {

@@ -260,6 +260,39 @@ class Conv3x3(nn.Conv2d):
         return super().forward(x)
 
 
+class _AddActionVector(torch.autograd.Function):
+    """bf16(h + table[actions]) on every pixel (mz_add_action_vector_bf16): the dynamics network's hidden state plus
+    the 1x1 convolution of the one-hot action planes (model.py:231-236).  h: bf16 [N, C, H, W] channels_last;
+    table: float32 [A, C]; actions: int32 [N]."""
+
+    @staticmethod
+    def forward(ctx, h, table, actions):
+        hh = h.permute(0, 2, 3, 1)
+        if not hh.is_contiguous() or h.dtype != torch.bfloat16:
+            raise ValueError("action vector: bf16 channels_last hidden state expected")
+        n, hgt, wid, c = hh.shape
+        out = torch.empty_like(hh)
+        _lib.call("mz_add_action_vector_bf16", _lib.ptr(hh), _lib.ptr(table), _lib.ptr(actions), _lib.ptr(out), n,
+                  hgt * wid, c, _lib.current_stream())
+        ctx.save_for_backward(actions)
+        ctx.n_actions = table.shape[0]
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (actions,) = ctx.saved_tensors
+        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dh = dy if ctx.needs_input_grad[0] else None
+        dtable = None
+        if ctx.needs_input_grad[1]:
+            n, c, hgt, wid = dy.shape
+            sums = torch.empty(n, c, dtype=torch.float32, device=dy.device)
+            dtable = torch.empty(ctx.n_actions, c, dtype=torch.float32, device=dy.device)
+            _lib.call("mz_action_vector_grad_bf16", _lib.ptr(dy.permute(0, 2, 3, 1)), _lib.ptr(actions), n, hgt * wid, c,
+                      ctx.n_actions, _lib.ptr(sums), _lib.ptr(dtable), _lib.current_stream())
+        return dh, dtable, None
+
+
 _BN_WS: Dict[tuple, torch.Tensor] = {}
 
 
@@ -446,7 +479,13 @@ class _Dynamics(nn.Module):
         """The next hidden state (model.py:231-241 without the reward head)."""
         # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
         w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
-        x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
+        if (self.conv_state.runs_native(h) and h.dtype == torch.bfloat16
+                and h.is_contiguous(memory_format=torch.channels_last)):
+            with torch.autocast("cuda", enabled=False):
+                table = (w.t() + self.conv_action.bias).float().contiguous()          # [A][width]
+                x = _AddActionVector.apply(h, table, action.reshape(-1).to(torch.int32))
+        else:
+            x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
         x = conv_bn_act(self.conv_state, self.bn, x)
         for b in self.resblocks:
             x = b(x)

@@ -500,3 +500,31 @@ def test_batchnorm_statistics_from_the_convolution():
     o = out.double().reshape(n, 144, 256)
     assert torch.allclose(stats[:, 0], o.sum(1), rtol=1e-6, atol=1e-5)
     assert torch.allclose(stats[:, 1], (o * o).sum(1), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,A", [(1, 6), (37, 18), (128, 18)])
+def test_action_vector_add_and_its_gradient_against_torch(N, A):
+    """hidden + conv_action(one-hot planes) (model.py:231-236) as mz_add_action_vector_bf16, and the gradient of the
+    per-action vectors (mz_action_vector_grad_bf16), through the autograd function the learner uses, against the
+    same expression in torch float32 on the same bf16 values; the gradient twice for identical bits."""
+    from muzero_amd.learner import _AddActionVector
+    g = torch.Generator().manual_seed(N)
+    C = 256
+    h = _bf16(torch.randn(N, C, 12, 12, generator=g)).cuda().contiguous(memory_format=torch.channels_last)
+    table = torch.randn(A, C, generator=g).cuda().requires_grad_(True)
+    actions = torch.randint(0, A, (N,), generator=g).cuda()
+    up = _bf16(torch.randn(N, C, 12, 12, generator=g)).cuda()
+    ha = h.clone().requires_grad_(True)
+    y = _AddActionVector.apply(ha, table, actions.to(torch.int32))
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    (y.float() * up.float()).sum().backward()
+    hb, tb = h.float().requires_grad_(True), table.detach().clone().requires_grad_(True)
+    yb = hb + tb[actions][:, :, None, None]
+    (yb * up.float()).sum().backward()
+    assert torch.equal(y, yb.to(torch.bfloat16))                                   # one rounding, the same one
+    assert torch.equal(ha.grad.float(), hb.grad)
+    assert (table.grad - tb.grad).abs().max().item() <= 1e-5 * tb.grad.abs().max().item() + 1e-5
+    first = table.grad.clone()
+    table.grad = None
+    (_AddActionVector.apply(ha, table, actions.to(torch.int32)).float() * up.float()).sum().backward()
+    assert torch.equal(first, table.grad)
