@@ -215,7 +215,7 @@ def test_full_size_update_native_against_torch_convolutions():
     for i in range(3):
         assert abs(nat[i] - ref[i]) <= 1e-3 * abs(ref[i]), (i, nat[i], ref[i])
     np.testing.assert_allclose(nat[3], ref[3], rtol=2e-3)
-    worst = 0.0
+    worst, tightest = 0.0, (0.0, "")
     total = float(np.sqrt(sum(float(g.norm()) ** 2 for g in ref[4].values())))
     for k, g in ref[4].items():
         n = float(g.norm())
@@ -226,9 +226,13 @@ def test_full_size_update_native_against_torch_convolutions():
         # both sides hold rounding noise there, hence the floor relative to the whole gradient; two runs of the SAME
         # path differ too - MIOpen's kernels for the other layer shapes accumulate in no fixed order - and the ratio
         # of the two noise norms has been seen between 0.8 and 1.27 for single parameters, hence the factor)
-        assert e_nat <= 1.35 * e_tor + 0.02 * n + 3e-4 * total, (k, e_nat, e_tor, n)
+        bound = 1.35 * e_tor + 0.02 * n + 3e-4 * total
+        assert e_nat <= bound, (k, e_nat, e_tor, n)
         worst = max(worst, e_nat / max(e_tor, 1e-12))
-    print(f"native bf16 error / torch bf16 error against the float32 gradients, worst parameter: {worst:.3f}")
+        if e_nat / bound > tightest[0]:
+            tightest = (e_nat / bound, k)
+    print(f"native bf16 error / torch bf16 error against the float32 gradients, worst parameter: {worst:.3f}; "
+          f"closest to its bound: {tightest[1]} at {tightest[0]:.2f} of it")
 
 
 def _train_cfg(B):
