@@ -458,17 +458,20 @@ int mz_nstep_targets(const double* rewards, const double* values, const double* 
                      const int32_t* q_pos, int32_t n_queries, int32_t K, int32_t td_steps, double gamma,
                      double* target_values, double* target_rewards, double* target_policies, mz_stream_t stream);
 
-/* The dynamics network's "hidden + conv_action(one-hot action planes)" (model.py:231-236) in the training step
- * (train.py:356-372), forward and the gradient of its parameters.  h, out, dy: bf16 NHWC [B][HW][C]; table: float
- * [A][C] = conv_action's weight column of each action + its bias (mz_action_vectors' layout); actions int32 [B],
- * 0 <= actions[b] < A guaranteed by the caller.  Forward: out = bf16(h + table[actions[b]]) on every pixel of
- * image b.  Gradient: dtable float [A][C] = sum over the images with that action and over their pixels of dy (the
- * gradient with respect to h is dy itself); image_sums: caller-owned float [B][C] scratch.  No atomics: the same
- * bits on every run. */
-int mz_add_action_vector_bf16(const void* h, const float* table, const int32_t* actions, void* out, int32_t B,
-                              int32_t HW, int32_t C, mz_stream_t stream);
-int mz_action_vector_grad_bf16(const void* dy, const int32_t* actions, int32_t B, int32_t HW, int32_t C, int32_t A,
-                               float* image_sums, float* dtable, mz_stream_t stream);
+/* What the unrolled training step (train.py:343-372) does with a hidden state besides convolving it, in one pass:
+ * mean_out float [B][C] = its spatial mean (the input of the prediction heads, model.py:273-281) and x_out =
+ * bf16(h + table[actions[b]]) on every pixel of image b - the dynamics network's "hidden + conv_action(one-hot
+ * action planes)" (model.py:231-236).  h, x_out: bf16 NHWC [B][HW][C]; table: float [A][C] = conv_action's
+ * weight column of each action + its bias (mz_action_vectors' layout); actions int32 [B], 0 <= actions[b] < A
+ * guaranteed by the caller.  Either output may be NULL (x_out == NULL needs neither table nor actions).
+ * Gradient: dh bf16 = dy + dmean / HW on every pixel (dy: gradient of x_out, dmean float [B][C]: gradient of
+ * mean_out; either may be NULL), and, when dtable is given, dtable float [A][C] = sum over the images with that
+ * action and over their pixels of dy (image_sums: caller-owned float [B][C] scratch).  C: 8 times a power of two,
+ * 32 to 2048.  No atomics: the same bits on every run. */
+int mz_step_input_bf16(const void* h, const float* table, const int32_t* actions, void* x_out, float* mean_out,
+                       int32_t B, int32_t HW, int32_t C, mz_stream_t stream);
+int mz_step_input_grad_bf16(const void* dy, const float* dmean, const int32_t* actions, int32_t B, int32_t HW, int32_t C,
+                            int32_t A, void* dh, float* image_sums, float* dtable, mz_stream_t stream);
 
 /* Weight gradient of a 3x3 convolution (padding 1) for the unrolled training step (compute_losses' backward
  * pass, train.py:303-308): dw float [Cout][Cin][3][3] = sum over images and output pixels of

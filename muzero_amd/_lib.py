@@ -91,8 +91,8 @@ _SIGNATURES = {
     "mz_comm_destroy": (C.c_int, [_P]),
     "mz_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32]),
     "mz_conv_wgrad_workspace_bytes_for": (C.c_int64, [C.c_int32] * 5),
-    "mz_add_action_vector_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int32] * 3 + [C.c_void_p]),
-    "mz_action_vector_grad_bf16": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int32] * 4 + [C.c_void_p] * 3),
+    "mz_step_input_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
+    "mz_step_input_grad_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4),
     "mz_packed_dgrad_s2_elems": (C.c_int64, [C.c_int32, C.c_int32]),
     "mz_weights_pack_dgrad_s2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "mz_conv_dgrad_s2_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]),

@@ -105,9 +105,11 @@ __global__ void nstep_targets_kernel(const double* __restrict__ rewards, const d
   }
 }
 
-// ---- "hidden + conv1x1(one-hot action planes)" of the dynamics network (model.py:231-236) in the training step:
-// on every pixel of image b the planes contribute table[actions[b]][c] (table = conv_action's weight column +
-// bias).  bf16 NHWC activations, float32 table; the sum is rounded to bf16 once.
+// ---- what the unrolled training step (train.py:343-372) does with a hidden state h_t besides convolving it, in one
+// pass over it: the spatial mean the prediction heads read (model.py:273-281) and the dynamics network's input
+// "hidden + conv1x1(one-hot action planes)" (model.py:231-236) - on every pixel of image b the planes contribute
+// table[actions[b]][c] (table = conv_action's weight column + bias).  bf16 NHWC activations, float32 table and
+// means; the sum is rounded to bf16 once.  One workgroup per image: thread = 8-channel group x row lane.
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
@@ -117,90 +119,173 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return (unsigned short)(u >> 16);
 }
 
-__global__ __launch_bounds__(256) void add_action_vector_kernel(const unsigned short* __restrict__ h,
-                                                               const float* __restrict__ table,
-                                                               const int* __restrict__ actions, long units, int per_image,
-                                                               int C, unsigned short* __restrict__ out) {
-  for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < units; u += (long)gridDim.x * 256) {
-    const int b = (int)(u / per_image), c8 = (int)(u % (C / 8));
-    const float* v = table + (long)actions[b] * C + c8 * 8;
-    const float4 v0 = *reinterpret_cast<const float4*>(v), v1 = *reinterpret_cast<const float4*>(v + 4);
-    const u16x8 x = *reinterpret_cast<const u16x8*>(h + u * 8);
-    u16x8 y;
-    y[0] = f32_to_bf16_bits(bf16_bits_to_f32(x[0]) + v0.x); y[1] = f32_to_bf16_bits(bf16_bits_to_f32(x[1]) + v0.y);
-    y[2] = f32_to_bf16_bits(bf16_bits_to_f32(x[2]) + v0.z); y[3] = f32_to_bf16_bits(bf16_bits_to_f32(x[3]) + v0.w);
-    y[4] = f32_to_bf16_bits(bf16_bits_to_f32(x[4]) + v1.x); y[5] = f32_to_bf16_bits(bf16_bits_to_f32(x[5]) + v1.y);
-    y[6] = f32_to_bf16_bits(bf16_bits_to_f32(x[6]) + v1.z); y[7] = f32_to_bf16_bits(bf16_bits_to_f32(x[7]) + v1.w);
-    *reinterpret_cast<u16x8*>(out + u * 8) = y;
-  }
-}
+constexpr int kStepThreads = 1024;   // 16 wavefronts per image: 32 row lanes at 256 channels, 4-5 rows each
 
-// Its gradient with respect to the table: dtable[a][c] = sum over the images b with actions[b] == a and over
-// their pixels of dy[b][pixel][c].  Two launches: per-image pixel sums (one workgroup per image: thread = channel
-// group x row lane, lanes combined through LDS), then per (a, c) the images in index order - no atomics, the
-// same bits every time.
-__global__ __launch_bounds__(256) void pixel_sum_kernel(const unsigned short* __restrict__ dy, int HW, int C,
-                                                       float* __restrict__ sums) {
-  __shared__ float red[256 * 8];
-  const int groups = C / 8, lanes = 256 / groups;
+// column sums of the workgroup's per-thread partials s[8] -> out[c] * scale, through LDS
+__device__ __forceinline__ void combine_row_lanes(float* red, const float (&s)[8], int groups, int lanes, int C,
+                                                  float scale, float* __restrict__ out) {
   const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
-  const unsigned short* img = dy + (long)blockIdx.x * HW * C;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (rl < lanes)
-    for (int r = rl; r < HW; r += lanes) {
-      const u16x8 v = *reinterpret_cast<const u16x8*>(img + (long)r * C + cg * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += bf16_bits_to_f32(v[j]);
-    }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) red[(rl * groups + cg) * 8 + j] = rl < lanes ? s[j] : 0.f;
+  for (int j = 0; j < 8; ++j) red[rl * C + cg * 8 + j] = s[j];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += kStepThreads) {
     float t = 0.f;
     for (int l = 0; l < lanes; ++l) t += red[l * C + c];
-    sums[(long)blockIdx.x * C + c] = t;
+    out[c] = t * scale;
   }
 }
 
+__global__ __launch_bounds__(kStepThreads) void step_input_kernel(const unsigned short* __restrict__ h,
+                                                        const float* __restrict__ table, const int* __restrict__ actions,
+                                                        int HW, int C, unsigned short* __restrict__ x_out,
+                                                        float* __restrict__ mean_out) {
+  __shared__ float red[kStepThreads * 8];
+  const int groups = C / 8, lanes = kStepThreads / groups;
+  const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+  const long base = (long)blockIdx.x * HW * C;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (x_out) {
+    const float* t = table + (long)actions[blockIdx.x] * C + cg * 8;
+    const float4 a = *reinterpret_cast<const float4*>(t), b = *reinterpret_cast<const float4*>(t + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // three rows per trip, their loads in flight together
+  for (int r0 = rl; r0 < HW; r0 += 3 * lanes) {
+    u16x8 in[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = r0 + k * lanes < HW ? r0 + k * lanes : r0;
+      in[k] = *reinterpret_cast<const u16x8*>(h + base + (long)r * C + cg * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = r0 + k * lanes;
+      if (r >= HW) break;
+      u16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf16_bits_to_f32(in[k][j]);
+        s[j] += f;
+        y[j] = f32_to_bf16_bits(f + v[j]);
+      }
+      if (x_out) *reinterpret_cast<u16x8*>(x_out + base + (long)r * C + cg * 8) = y;
+    }
+  }
+  if (mean_out) combine_row_lanes(red, s, groups, lanes, C, 1.f / (float)HW, mean_out + (long)blockIdx.x * C);
+}
+
+// The gradient of both: dh = bf16(dy + dmean / HW) on every pixel (either term may be absent), and per image the
+// pixel sums of dy, from which dtable[a][c] = sum over the images with actions[b] == a, in index order - no
+// atomics, the same bits every time.
+__global__ __launch_bounds__(kStepThreads) void step_input_grad_kernel(const unsigned short* __restrict__ dy,
+                                                             const float* __restrict__ dmean, int HW, int C,
+                                                             unsigned short* __restrict__ dh,
+                                                             float* __restrict__ image_sums) {
+  __shared__ float red[kStepThreads * 8];
+  const int groups = C / 8, lanes = kStepThreads / groups;
+  const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+  const long base = (long)blockIdx.x * HW * C;
+  float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (dmean) {
+    const float* t = dmean + (long)blockIdx.x * C + cg * 8;
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = t[j] * inv;
+  }
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r0 = rl; r0 < HW; r0 += 3 * lanes) {  // three rows per trip, as in step_input_kernel
+    u16x8 in[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = r0 + k * lanes < HW ? r0 + k * lanes : r0;
+      in[k] = u16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (dy) in[k] = *reinterpret_cast<const u16x8*>(dy + base + (long)r * C + cg * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = r0 + k * lanes;
+      if (r >= HW) break;
+      u16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf16_bits_to_f32(in[k][j]);
+        s[j] += f;
+        y[j] = f32_to_bf16_bits(f + m[j]);
+      }
+      *reinterpret_cast<u16x8*>(dh + base + (long)r * C + cg * 8) = y;
+    }
+  }
+  if (image_sums) combine_row_lanes(red, s, groups, lanes, C, 1.f, image_sums + (long)blockIdx.x * C);
+}
+
+// dtable[a][c]: one workgroup per (action, 32 channels); thread = channel x one of 8 image lanes that adds every
+// eighth image (all loads unconditional and in flight together, the action test picks what counts), the lanes
+// combined in a fixed order.
 __global__ __launch_bounds__(256) void action_group_sum_kernel(const float* __restrict__ sums,
                                                               const int* __restrict__ actions, int B, int C, int A,
                                                               float* __restrict__ dtable) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= A * C) return;
-  const int a = i / C, c = i - a * C;
+  __shared__ float red[8][32];
+  const int per_a = C / 32;
+  const int a = blockIdx.x / per_a, c = (blockIdx.x % per_a) * 32 + (threadIdx.x & 31), bl = threadIdx.x >> 5;
   float t = 0.f;
-  for (int b = 0; b < B; ++b)
-    if (actions[b] == a) t += sums[(long)b * C + c];
-  dtable[i] = t;
+  for (int b0 = bl; b0 < B; b0 += 64) {
+    float v[8];
+    int act[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = b0 + 8 * k < B ? b0 + 8 * k : b0;
+      v[k] = sums[(long)b * C + c];
+      act[k] = actions[b];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (b0 + 8 * k < B && act[k] == a) t += v[k];
+  }
+  red[bl][threadIdx.x & 31] = t;
+  __syncthreads();
+  if (bl == 0) {
+    float r = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) r += red[l][threadIdx.x];
+    dtable[(long)a * C + c] = r;
+  }
+}
+
+int check_step_shape(const char* who, int32_t B, int32_t HW, int32_t C) {
+  MZ_REQUIRE(B > 0 && HW > 0, "%s: empty batch", who);
+  MZ_REQUIRE(C >= 32 && C % 32 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0,
+             "%s: C = %d must be 8 times a power of two, from 32 to 2048", who, C);
+  return MZ_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-int mz_add_action_vector_bf16(const void* h, const float* table, const int32_t* actions, void* out, int32_t B,
-                              int32_t HW, int32_t C, mz_stream_t stream) {
-  MZ_REQUIRE(h && table && actions && out && B > 0 && HW > 0, "mz_add_action_vector_bf16: null tensor or empty batch");
-  MZ_REQUIRE(C >= 8 && C % 8 == 0, "mz_add_action_vector_bf16: C = %d must be a multiple of 8", C);
-  const long units = (long)B * HW * (C / 8);
-  const long want = (units + 255) / 256, cap = 8L * mz::compute_units();
-  hipLaunchKernelGGL(add_action_vector_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0,
-                     mz::as_stream(stream), static_cast<const unsigned short*>(h), table, actions, units, HW * (C / 8), C,
-                     static_cast<unsigned short*>(out));
-  return mz::check_launch("mz_add_action_vector_bf16");
+int mz_step_input_bf16(const void* h, const float* table, const int32_t* actions, void* x_out, float* mean_out,
+                       int32_t B, int32_t HW, int32_t C, mz_stream_t stream) {
+  MZ_REQUIRE(h && (x_out || mean_out), "mz_step_input_bf16: null tensor");
+  MZ_REQUIRE(!x_out || (table && actions), "mz_step_input_bf16: x_out needs table and actions");
+  if (int rc = check_step_shape("mz_step_input_bf16", B, HW, C)) return rc;
+  hipLaunchKernelGGL(step_input_kernel, dim3(B), dim3(kStepThreads), 0, mz::as_stream(stream),
+                     static_cast<const unsigned short*>(h), table, actions, HW, C, static_cast<unsigned short*>(x_out),
+                     mean_out);
+  return mz::check_launch("mz_step_input_bf16");
 }
 
-int mz_action_vector_grad_bf16(const void* dy, const int32_t* actions, int32_t B, int32_t HW, int32_t C, int32_t A,
-                               float* image_sums, float* dtable, mz_stream_t stream) {
-  MZ_REQUIRE(dy && actions && image_sums && dtable && B > 0 && HW > 0 && A > 0,
-             "mz_action_vector_grad_bf16: null tensor or empty batch");
-  MZ_REQUIRE(C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0,
-             "mz_action_vector_grad_bf16: C = %d must be 8 times a power of two, at most 2048", C);
+int mz_step_input_grad_bf16(const void* dy, const float* dmean, const int32_t* actions, int32_t B, int32_t HW, int32_t C,
+                            int32_t A, void* dh, float* image_sums, float* dtable, mz_stream_t stream) {
+  MZ_REQUIRE(dh && (dy || dmean), "mz_step_input_grad_bf16: null tensor");
+  MZ_REQUIRE(!dtable || (dy && actions && image_sums && A > 0),
+             "mz_step_input_grad_bf16: dtable needs dy, actions, image_sums and A > 0");
+  if (int rc = check_step_shape("mz_step_input_grad_bf16", B, HW, C)) return rc;
   hipStream_t s = mz::as_stream(stream);
-  hipLaunchKernelGGL(pixel_sum_kernel, dim3(B), dim3(256), 0, s, static_cast<const unsigned short*>(dy), HW, C, image_sums);
-  hipLaunchKernelGGL(action_group_sum_kernel, dim3((A * C + 255) / 256), dim3(256), 0, s, image_sums, actions, B, C, A,
-                     dtable);
-  return mz::check_launch("mz_action_vector_grad_bf16");
+  hipLaunchKernelGGL(step_input_grad_kernel, dim3(B), dim3(kStepThreads), 0, s, static_cast<const unsigned short*>(dy), dmean, HW,
+                     C, static_cast<unsigned short*>(dh), dtable ? image_sums : nullptr);
+  if (dtable)
+    hipLaunchKernelGGL(action_group_sum_kernel, dim3(A * (C / 32)), dim3(256), 0, s, image_sums, actions, B, C, A, dtable);
+  return mz::check_launch("mz_step_input_grad_bf16");
 }
 
 int mz_support_ce(const float* logits, const float* targets, int32_t n, int32_t S, float* loss, float* dlogits,

@@ -260,37 +260,78 @@ class Conv3x3(nn.Conv2d):
         return super().forward(x)
 
 
-class _AddActionVector(torch.autograd.Function):
-    """bf16(h + table[actions]) on every pixel (mz_add_action_vector_bf16): the dynamics network's hidden state plus
-    the 1x1 convolution of the one-hot action planes (model.py:231-236).  h: bf16 [N, C, H, W] channels_last;
-    table: float32 [A, C]; actions: int32 [N]."""
+def _nhwc(t):
+    th = t.permute(0, 2, 3, 1)
+    if not th.is_contiguous() or t.dtype != torch.bfloat16:
+        raise ValueError("bf16 channels_last activations expected")
+    return th
+
+
+class _StepInput(torch.autograd.Function):
+    """One pass over a hidden state h (mz_step_input_bf16): x = bf16(h + table[actions]) on every pixel - the dynamics
+    network's hidden state plus the 1x1 convolution of the one-hot action planes (model.py:231-236) - and the
+    spatial mean of h that the prediction heads read (model.py:273-281).  h: bf16 [N, C, H, W] channels_last;
+    table: float32 [A, C]; actions: int32 [N].  Returns (x, mean float32 [N, C])."""
 
     @staticmethod
     def forward(ctx, h, table, actions):
-        hh = h.permute(0, 2, 3, 1)
-        if not hh.is_contiguous() or h.dtype != torch.bfloat16:
-            raise ValueError("action vector: bf16 channels_last hidden state expected")
+        hh = _nhwc(h)
         n, hgt, wid, c = hh.shape
-        out = torch.empty_like(hh)
-        _lib.call("mz_add_action_vector_bf16", _lib.ptr(hh), _lib.ptr(table), _lib.ptr(actions), _lib.ptr(out), n,
+        x = torch.empty_like(hh)
+        mean = torch.empty(n, c, dtype=torch.float32, device=h.device)
+        _lib.call("mz_step_input_bf16", _lib.ptr(hh), _lib.ptr(table), _lib.ptr(actions), _lib.ptr(x), _lib.ptr(mean), n,
                   hgt * wid, c, _lib.current_stream())
         ctx.save_for_backward(actions)
-        ctx.n_actions = table.shape[0]
-        return out.permute(0, 3, 1, 2)
+        ctx.shape, ctx.n_actions = (n, hgt, wid, c), table.shape[0]
+        ctx.set_materialize_grads(False)
+        return x.permute(0, 3, 1, 2), mean
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dx, dmean):
         (actions,) = ctx.saved_tensors
-        dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        dh = dy if ctx.needs_input_grad[0] else None
-        dtable = None
+        n, hgt, wid, c = ctx.shape
+        if dx is None and dmean is None:
+            return None, None, None
+        dev = actions.device
+        if dx is not None:
+            dx = _nhwc(dx.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        if dmean is not None:
+            dmean = dmean.float().contiguous()
+        dh = torch.empty(n, hgt, wid, c, dtype=torch.bfloat16, device=dev)
+        sums = dtable = None
         if ctx.needs_input_grad[1]:
-            n, c, hgt, wid = dy.shape
-            sums = torch.empty(n, c, dtype=torch.float32, device=dy.device)
-            dtable = torch.empty(ctx.n_actions, c, dtype=torch.float32, device=dy.device)
-            _lib.call("mz_action_vector_grad_bf16", _lib.ptr(dy.permute(0, 2, 3, 1)), _lib.ptr(actions), n, hgt * wid, c,
-                      ctx.n_actions, _lib.ptr(sums), _lib.ptr(dtable), _lib.current_stream())
-        return dh, dtable, None
+            dtable = torch.empty(ctx.n_actions, c, dtype=torch.float32, device=dev)
+            if dx is None:
+                dtable.zero_()
+            else:
+                sums = torch.empty(n, c, dtype=torch.float32, device=dev)
+        _lib.call("mz_step_input_grad_bf16", _lib.ptr(dx), _lib.ptr(dmean), _lib.ptr(actions), n, hgt * wid, c,
+                  ctx.n_actions, _lib.ptr(dh), _lib.ptr(sums), _lib.ptr(dtable if sums is not None else None),
+                  _lib.current_stream())
+        return dh.permute(0, 3, 1, 2), dtable, None
+
+
+class _PixelMean(torch.autograd.Function):
+    """The spatial mean of a bf16 channels_last hidden state as float32 [N, C] (the same kernel without the
+    action vector)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        hh = _nhwc(h)
+        n, hgt, wid, c = hh.shape
+        mean = torch.empty(n, c, dtype=torch.float32, device=h.device)
+        _lib.call("mz_step_input_bf16", _lib.ptr(hh), None, None, None, _lib.ptr(mean), n, hgt * wid, c,
+                  _lib.current_stream())
+        ctx.shape = (n, hgt, wid, c)
+        return mean
+
+    @staticmethod
+    def backward(ctx, dmean):
+        n, hgt, wid, c = ctx.shape
+        dh = torch.empty(n, hgt, wid, c, dtype=torch.bfloat16, device=dmean.device)
+        _lib.call("mz_step_input_grad_bf16", None, _lib.ptr(dmean.float().contiguous()), None, n, hgt * wid, c, 0,
+                  _lib.ptr(dh), None, None, _lib.current_stream())
+        return dh.permute(0, 3, 1, 2)
 
 
 _BN_WS: Dict[tuple, torch.Tensor] = {}
@@ -475,21 +516,32 @@ class _Dynamics(nn.Module):
         self.resblocks = nn.ModuleList([_Res(width) for _ in range(n_blocks)])
         self.reward_head = _mlp(width, fc_reward, 2 * support + 1)
 
-    def trunk(self, h, action):
-        """The next hidden state (model.py:231-241 without the reward head)."""
-        # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
-        w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
-        if (self.conv_state.runs_native(h) and h.dtype == torch.bfloat16
-                and h.is_contiguous(memory_format=torch.channels_last)):
-            with torch.autocast("cuda", enabled=False):
-                table = (w.t() + self.conv_action.bias).float().contiguous()          # [A][width]
-                x = _AddActionVector.apply(h, table, action.reshape(-1).to(torch.int32))
-        else:
-            x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
+    def fused_input(self, h) -> bool:
+        """Whether h can go through the one-pass kernel (native bf16 path, channels_last hidden state)."""
+        return (self.conv_state.runs_native(h) and h.dtype == torch.bfloat16
+                and h.is_contiguous(memory_format=torch.channels_last))
+
+    def step_input(self, h, action):
+        """(hidden + conv1x1(one-hot planes), spatial mean of hidden) in one pass (see _StepInput)."""
+        with torch.autocast("cuda", enabled=False):
+            w = self.conv_action.weight[:, :, 0, 0]                                   # [width][A]
+            table = (w.t() + self.conv_action.bias).float().contiguous()              # [A][width]
+            return _StepInput.apply(h, table, action.reshape(-1).to(torch.int32))
+
+    def trunk_from(self, x):
         x = conv_bn_act(self.conv_state, self.bn, x)
         for b in self.resblocks:
             x = b(x)
         return x
+
+    def trunk(self, h, action):
+        """The next hidden state (model.py:231-241 without the reward head)."""
+        # hidden + conv1x1(one-hot planes) == hidden + W[:, action] + bias on every pixel
+        if self.fused_input(h):
+            return self.trunk_from(self.step_input(h, action)[0])
+        w = self.conv_action.weight[:, :, 0, 0]                      # [width][A]
+        x = h + (w.t()[action.view(-1)] + self.conv_action.bias)[:, :, None, None]
+        return self.trunk_from(x)
 
     def forward(self, h, action):
         x = self.trunk(h, action)
@@ -535,10 +587,17 @@ class TrainableNetwork(nn.Module):
         gradient-accumulation adds of an update.  actions: int64 [B, K].  Returns the policy and value logits
         [(K+1) B, .] (step-major: rows t B .. (t+1) B - 1 are step t) and the reward logits [K B, .] (steps 1..K)."""
         h = self.representation(obs)
-        means = [h.mean(dim=(2, 3))]
+        dyn = self.dynamics
+        means = []
         for t in range(actions.shape[1]):
-            h = self.dynamics.trunk(h, actions[:, t])
-            means.append(h.mean(dim=(2, 3)))
+            if dyn.fused_input(h):           # the step's input and the heads' mean from one pass over h
+                x, mean = dyn.step_input(h, actions[:, t])
+                means.append(mean)
+                h = dyn.trunk_from(x)
+            else:
+                means.append(h.mean(dim=(2, 3)))
+                h = dyn.trunk(h, actions[:, t])
+        means.append(_PixelMean.apply(h) if dyn.fused_input(h) else h.mean(dim=(2, 3)))
         m = torch.cat(means)
         policy, value = self.prediction.policy_head(m), self.prediction.value_head(m)
         reward = self.dynamics.reward_head(m[means[0].shape[0]:]) if len(means) > 1 else None

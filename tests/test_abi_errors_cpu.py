@@ -74,8 +74,10 @@ def test_null_and_shape_errors_are_reported_not_crashed():
     _fails("mz_weights_fold_pack", one, None, None, None, None, None, 1e-5, 256, 256, 256, 4, 0, 0, one, None, None,
            match="mode")
     _fails("mz_pack_linear", one, None, 601, 256, 3, one, None, None, match="format")
-    _fails("mz_add_action_vector_bf16", one, one, one, one, 4, 144, 100, None, match="multiple of 8")
-    _fails("mz_action_vector_grad_bf16", one, one, 4, 144, 24, 18, one, one, None, match="power of two")
+    _fails("mz_step_input_bf16", one, None, None, one, one, 4, 144, 256, None, match="needs table and actions")
+    _fails("mz_step_input_bf16", one, one, one, one, one, 4, 144, 24, None, match="power of two")
+    _fails("mz_step_input_grad_bf16", None, None, None, 4, 144, 256, 18, one, None, None, None, match="null tensor")
+    _fails("mz_step_input_grad_bf16", one, None, None, 4, 144, 256, 18, one, None, one, None, match="dtable needs")
     # the stride-2 data gradient and its packing
     _fails("mz_conv_dgrad_s2_bf16", None, one, one, 4, 48, 48, 256, 128, None, match="null tensor")
     _fails("mz_conv_dgrad_s2_bf16", one, one, one, 4, 96, 96, 96, 256, None, match="no kernel")

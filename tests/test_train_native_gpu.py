@@ -507,28 +507,59 @@ def test_batchnorm_statistics_from_the_convolution():
 
 
 @pytest.mark.parametrize("N,A", [(1, 6), (37, 18), (128, 18)])
-def test_action_vector_add_and_its_gradient_against_torch(N, A):
-    """hidden + conv_action(one-hot planes) (model.py:231-236) as mz_add_action_vector_bf16, and the gradient of the
-    per-action vectors (mz_action_vector_grad_bf16), through the autograd function the learner uses, against the
-    same expression in torch float32 on the same bf16 values; the gradient twice for identical bits."""
-    from muzero_amd.learner import _AddActionVector
+def test_step_input_and_its_gradient_against_torch(N, A):
+    """hidden + conv_action(one-hot planes) (model.py:231-236) and the spatial mean the heads read (model.py:273-281)
+    from one pass over the hidden state (mz_step_input_bf16), and their gradients (mz_step_input_grad_bf16), through
+    the autograd functions the learner uses, against the same expressions in torch float32 on the same bf16 values;
+    the gradient twice for identical bits; each output alone."""
+    from muzero_amd.learner import _PixelMean, _StepInput
     g = torch.Generator().manual_seed(N)
     C = 256
     h = _bf16(torch.randn(N, C, 12, 12, generator=g)).cuda().contiguous(memory_format=torch.channels_last)
     table = torch.randn(A, C, generator=g).cuda().requires_grad_(True)
     actions = torch.randint(0, A, (N,), generator=g).cuda()
-    up = _bf16(torch.randn(N, C, 12, 12, generator=g)).cuda()
-    ha = h.clone().requires_grad_(True)
-    y = _AddActionVector.apply(ha, table, actions.to(torch.int32))
-    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
-    (y.float() * up.float()).sum().backward()
-    hb, tb = h.float().requires_grad_(True), table.detach().clone().requires_grad_(True)
-    yb = hb + tb[actions][:, :, None, None]
-    (yb * up.float()).sum().backward()
-    assert torch.equal(y, yb.to(torch.bfloat16))                                   # one rounding, the same one
-    assert torch.equal(ha.grad.float(), hb.grad)
-    assert (table.grad - tb.grad).abs().max().item() <= 1e-5 * tb.grad.abs().max().item() + 1e-5
-    first = table.grad.clone()
+    a32 = actions.to(torch.int32)
+    up = _bf16(torch.randn(N, C, 12, 12, generator=g)).cuda().float()
+    upm = torch.randn(N, C, generator=g).cuda()
+
+    def reference(use_x, use_mean):
+        hb, tb = h.float().requires_grad_(True), table.detach().clone().requires_grad_(True)
+        xb = hb + tb[actions][:, :, None, None]
+        mb = hb.mean(dim=(2, 3))
+        ((xb * up).sum() * use_x + (mb * upm).sum() * use_mean).backward()
+        return xb, mb, hb.grad, tb.grad if use_x else torch.zeros_like(tb)
+
+    for use_x, use_mean in ((1, 1), (1, 0), (0, 1)):
+        ha = h.clone().requires_grad_(True)
+        table.grad = None
+        x, m = _StepInput.apply(ha, table, a32)
+        assert x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and m.dtype == torch.float32
+        loss = 0
+        if use_x:
+            loss = loss + (x.float() * up).sum()
+        if use_mean:
+            loss = loss + (m * upm).sum()
+        loss.backward()
+        xb, mb, dh, dt = reference(use_x, use_mean)
+        assert torch.equal(x, xb.to(torch.bfloat16))                               # one rounding, the same one
+        assert (m - mb).abs().max().item() <= 1e-5 * mb.abs().max().item() + 1e-6
+        # dh is rounded to bf16 once
+        assert (ha.grad.float() - dh).abs().max().item() <= 4e-3 * dh.abs().max().item()
+        got_dt = table.grad if table.grad is not None else torch.zeros_like(table)
+        assert (got_dt - dt).abs().max().item() <= 1e-5 * dt.abs().max().item() + 1e-5
+    first = table.grad
     table.grad = None
-    (_AddActionVector.apply(ha, table, actions.to(torch.int32)).float() * up.float()).sum().backward()
-    assert torch.equal(first, table.grad)
+    ha = h.clone().requires_grad_(True)
+    (_StepInput.apply(ha, table, a32)[0].float() * up).sum().backward()
+    first_x = table.grad.clone()
+    table.grad = None
+    (_StepInput.apply(ha, table, a32)[0].float() * up).sum().backward()
+    assert torch.equal(first_x, table.grad)
+    # the mean alone (the last hidden state of an unroll)
+    ha = h.clone().requires_grad_(True)
+    m = _PixelMean.apply(ha)
+    (m * upm).sum().backward()
+    hb = h.float().requires_grad_(True)
+    (hb.mean(dim=(2, 3)) * upm).sum().backward()
+    assert (m - hb.mean(dim=(2, 3))).abs().max().item() <= 1e-5 * m.abs().max().item() + 1e-6
+    assert (ha.grad.float() - hb.grad).abs().max().item() <= 4e-3 * hb.grad.abs().max().item()
