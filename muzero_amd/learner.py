@@ -521,11 +521,18 @@ class _Dynamics(nn.Module):
         return (self.conv_state.runs_native(h) and h.dtype == torch.bfloat16
                 and h.is_contiguous(memory_format=torch.channels_last))
 
-    def step_input(self, h, action):
-        """(hidden + conv1x1(one-hot planes), spatial mean of hidden) in one pass (see _StepInput)."""
+    def action_table(self):
+        """float32 [A][width]: what conv_action adds to every pixel for each action (weight column + bias)."""
         with torch.autocast("cuda", enabled=False):
             w = self.conv_action.weight[:, :, 0, 0]                                   # [width][A]
-            table = (w.t() + self.conv_action.bias).float().contiguous()              # [A][width]
+            return (w.t() + self.conv_action.bias).float().contiguous()
+
+    def step_input(self, h, action, table=None):
+        """(hidden + conv1x1(one-hot planes), spatial mean of hidden) in one pass (see _StepInput).  table: the
+        result of ``action_table()`` when the caller applies the network several times per pass."""
+        if table is None:
+            table = self.action_table()
+        with torch.autocast("cuda", enabled=False):
             return _StepInput.apply(h, table, action.reshape(-1).to(torch.int32))
 
     def trunk_from(self, x):
@@ -589,9 +596,10 @@ class TrainableNetwork(nn.Module):
         h = self.representation(obs)
         dyn = self.dynamics
         means = []
+        table = dyn.action_table() if dyn.fused_input(h) else None      # once per pass: its gradient is summed first
         for t in range(actions.shape[1]):
             if dyn.fused_input(h):           # the step's input and the heads' mean from one pass over h
-                x, mean = dyn.step_input(h, actions[:, t])
+                x, mean = dyn.step_input(h, actions[:, t], table)
                 means.append(mean)
                 h = dyn.trunk_from(x)
             else:
