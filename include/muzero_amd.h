@@ -543,6 +543,13 @@ int mz_conv3x3_bf16_stats(const void* in, const void* wpk, const float* bias, vo
 int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
                          const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx, void* dresidual,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mz_stream_t stream);
+/* The same with accumulate != 0: dgamma and dbeta are ADDED to what the buffers hold (float32) - a layer applied at
+ * every unroll step (the dynamics network's, train.py:356-372) sums its steps' gradients without a launch per
+ * addition; accumulate == 0 is mz_bn_relu_train_bwd. */
+int mz_bn_relu_train_bwd_acc(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
+                             const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx,
+                             void* dresidual, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                             int64_t workspace_bytes, mz_stream_t stream);
 
 /* ReplayBuffer.sample_batch's draw (model.py:580-588) on device-resident priorities: double prio [n], one per
  * stored position, oldest game first.  u: double [batch], the [0,1) draws np.random.choice would consume.

@@ -105,6 +105,8 @@ _SIGNATURES = {
                                                      _P, C.c_int32, _P, C.c_int64, _P]),
     "mz_conv3x3_bf16_stats": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P]),
     "mz_bn_relu_train_bwd": (C.c_int, [_P] * 6 + [C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "mz_bn_relu_train_bwd_acc": (C.c_int, [_P] * 6 + [C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, C.c_int32, _P,
+                                           C.c_int64, _P]),
     "mz_replay_workspace_bytes": (C.c_int64, [C.c_int64]),
     "mz_replay_sample": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_double, _P, C.c_int32, _P, _P, _P, _P, _P,
                                    C.c_int64, _P]),

@@ -201,13 +201,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const unsigned short* __r
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int blocks, long rows, int C,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef) {
+                                       float* __restrict__ coef, int accumulate) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7), lane = threadIdx.x >> 3;
   double sg, sgx;
   sum_partials(partial, blocks, C, c, lane, sg, sgx);
   if (c >= C || lane != 0) return;
-  dbeta[c] = (float)sg;
-  dgamma[c] = (float)sgx;
+  // accumulate: a layer applied at several unroll steps adds each step's gradient to the running sum (the same
+  // float32 additions, in the same order, that autograd's accumulation would make - without a launch each)
+  dbeta[c] = accumulate ? dbeta[c] + (float)sg : (float)sg;
+  dgamma[c] = accumulate ? dgamma[c] + (float)sgx : (float)sgx;
   coef[c] = gamma[c] * invstd[c];
   coef[C + c] = (float)(sg / (double)rows);
   coef[2 * C + c] = (float)(sgx / (double)rows);
@@ -324,9 +326,22 @@ int mz_bn_relu_train_fwd_stats(const void* x, const void* residual, const float*
                 rows, C, y, save_mean, save_invstd, stats, stat_blocks, workspace, workspace_bytes, stream);
 }
 
+int mz_bn_relu_train_bwd_acc(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
+                             const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx,
+                             void* dresidual, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                             int64_t workspace_bytes, mz_stream_t stream);
+
 int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
                          const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx, void* dresidual,
                          float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, mz_stream_t stream) {
+  return mz_bn_relu_train_bwd_acc(x, dy, y, gamma, save_mean, save_invstd, relu, rows, C, dx, dresidual, dgamma, dbeta, 0,
+                                  workspace, workspace_bytes, stream);
+}
+
+int mz_bn_relu_train_bwd_acc(const void* x, const void* dy, const void* y, const float* gamma, const float* save_mean,
+                             const float* save_invstd, int32_t relu, int64_t rows, int32_t C, void* dx,
+                             void* dresidual, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                             int64_t workspace_bytes, mz_stream_t stream) {
   MZ_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
              "mz_bn_relu_train_bwd: null argument");
   MZ_REQUIRE(!relu || y, "mz_bn_relu_train_bwd: the ReLU mask needs the forward output y");
@@ -343,7 +358,7 @@ int mz_bn_relu_train_bwd(const void* x, const void* dy, const void* y, const flo
   hipLaunchKernelGGL(bn_colsum_kernel<1>, dim3(blocks), dim3(kStatsThreads), (size_t)lanes * 2 * C * 8, s, xs, gs, ys,
                      save_mean, save_invstd, relu, (long)rows, C, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(256), 0, s, partial, blocks, (long)rows, C, gamma,
-                     save_invstd, dgamma, dbeta, coef);
+                     save_invstd, dgamma, dbeta, coef, accumulate ? 1 : 0);
   const long units = rows * (C / 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(apply_blocks(units)), dim3(256), 0, s, xs, gs, ys, save_mean,
                      save_invstd, coef, relu, units, C, static_cast<unsigned short*>(dx),

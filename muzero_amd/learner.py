@@ -345,12 +345,26 @@ def _bn_workspace(C: int, device) -> torch.Tensor:
     return t
 
 
+class _BNGradSum:
+    """The running sums of one BatchNorm layer's weight / bias gradients over the unroll steps of a pass
+    (mz_bn_relu_train_bwd_acc adds each step's into them); ``Learner._backward`` hands them to the parameters."""
+
+    def __init__(self):
+        self.dgamma = self.dbeta = None
+        self.active = False          # set around loss.backward() by Learner._backward; otherwise autograd sums
+
+    def take(self):
+        out, self.dgamma, self.dbeta = (self.dgamma, self.dbeta), None, None
+        return out
+
+
 class _BNActNative(torch.autograd.Function):
     """relu(batch_norm(x) [+ residual]) in training mode on this library's kernels (mz_bn_relu_train_fwd / _bwd).
-    x, residual: bf16 [N, C, H, W] in channels_last memory.  Running statistics are updated in place."""
+    x, residual: bf16 [N, C, H, W] in channels_last memory.  Running statistics are updated in place.
+    grad_sum (a _BNGradSum or None): where the affine parameters' gradients are summed instead of being returned."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, stats=None):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, stats=None, grad_sum=None):
         n, c, h, w = x.shape
         rows = n * h * w
         y = torch.empty_like(x)                       # keeps the channels_last strides
@@ -370,6 +384,7 @@ class _BNActNative(torch.autograd.Function):
                       stats.shape[0], _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
         ctx.save_for_backward(x, y, gamma, save_mean, save_invstd)
         ctx.has_residual = residual is not None
+        ctx.grad_sum = grad_sum
         return y
 
     @staticmethod
@@ -379,13 +394,23 @@ class _BNActNative(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_residual else None
-        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty_like(dgamma)
+        acc = ctx.grad_sum if ctx.grad_sum is not None and ctx.grad_sum.active else None
+        first = acc is None or acc.dgamma is None
+        if first:
+            dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+            dbeta = torch.empty_like(dgamma)
+            if acc is not None:
+                acc.dgamma, acc.dbeta = dgamma, dbeta
+        else:
+            dgamma, dbeta = acc.dgamma, acc.dbeta
         ws = _bn_workspace(c, x.device)
-        _lib.call("mz_bn_relu_train_bwd", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
+        _lib.call("mz_bn_relu_train_bwd_acc", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(y), _lib.ptr(gamma.detach()),
                   _lib.ptr(save_mean), _lib.ptr(save_invstd), 1, n * h * w, c, _lib.ptr(dx), _lib.ptr(dres),
-                  _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ws), ws.numel() * 8, _lib.current_stream())
-        return dx, dres, dgamma, dbeta, None, None, None, None, None
+                  _lib.ptr(dgamma), _lib.ptr(dbeta), 0 if first else 1, _lib.ptr(ws), ws.numel() * 8,
+                  _lib.current_stream())
+        if acc is not None:
+            dgamma = dbeta = None            # handed over by Learner._backward once the pass is through
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
 
 _BN_COUNTS: Optional[dict] = None
@@ -437,7 +462,7 @@ def bn_act(bn: nn.BatchNorm2d, x, residual=None, stats=None):
             else:
                 bn.num_batches_tracked.add_(1)
             return _BNActNative.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                                      bn.momentum, stats)
+                                      bn.momentum, stats, getattr(bn, "grad_sum", None))
     if stats is not None:
         raise ValueError("column sums are for the fused BatchNorm path only")
     y = bn(x)
@@ -1074,6 +1099,10 @@ class Learner:
         for m in self.network.modules():
             if isinstance(m, (Conv3x3, nn.BatchNorm2d)):
                 m.native = self.native_convs
+        if self.native_convs:       # the dynamics network's BatchNorms run once per unroll step (see _backward)
+            for m in self.network.dynamics.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.grad_sum = _BNGradSum()
         self.optimizer = torch.optim.SGD(self.network.parameters(), lr=config.lr_init, momentum=config.momentum,
                                          weight_decay=config.weight_decay)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=config.lr_decay_steps,
@@ -1282,18 +1311,31 @@ class Learner:
                 m._packed.mark_current(m.weight, t)
 
     def _backward(self, loss) -> None:
-        """loss.backward() with the weight gradients of the dynamics network's native convolutions - applied
-        once per unroll step - computed by one kernel pass per layer over all steps instead of one per step."""
-        convs = [m for m in self.network.dynamics.modules() if isinstance(m, Conv3x3)] if self.native_convs else []
+        """loss.backward() with the gradients of the dynamics network's layers - applied once per unroll step -
+        summed by this library instead of by autograd: the native convolutions' weight gradients come from one
+        kernel pass per layer over all steps, the fused BatchNorms add each step's affine gradients into a running
+        sum."""
+        mods = list(self.network.dynamics.modules()) if self.native_convs else []
+        convs = [m for m in mods if isinstance(m, Conv3x3)]
+        norms = [m for m in mods if isinstance(m, nn.BatchNorm2d) and getattr(m, "grad_sum", None) is not None]
         for m in convs:
             m.defer_wgrad(True)
+        for m in norms:
+            m.grad_sum.active = True
         try:
             loss.backward()
             for m in convs:
                 m.flush_wgrad()
+            for m in norms:
+                for p, g in zip((m.weight, m.bias), m.grad_sum.take()):
+                    if g is not None and p.requires_grad:
+                        p.grad = g if p.grad is None else p.grad + g
         finally:
             for m in convs:
                 m.defer_wgrad(False)
+            for m in norms:
+                m.grad_sum.take()
+                m.grad_sum.active = False
 
     def _step(self, v, r, p, per):
         loss = per.mean()

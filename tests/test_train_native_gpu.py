@@ -419,8 +419,9 @@ def test_wgrad_over_several_segments_equals_the_sum_of_single_calls():
 
 
 def test_deferred_weight_gradients_equal_the_per_step_ones():
-    """Learner._backward (the dynamics convolutions' weight gradients from one kernel pass over all unroll steps)
-    against a plain loss.backward() (one pass per step, summed by autograd) on the same network and batch."""
+    """Learner._backward (the dynamics convolutions' weight gradients from one kernel pass over all unroll steps,
+    the dynamics BatchNorms' affine gradients summed inside their backward kernel) against a plain
+    loss.backward() (one pass per step, summed by autograd) on the same network and batch."""
     from muzero_amd.config import MuZeroConfig
     from muzero_amd.learner import Learner
     from muzero_amd.network import init_state_dict
@@ -450,6 +451,9 @@ def test_deferred_weight_gradients_equal_the_per_step_ones():
         tol = 1e-4 if k.startswith("dynamics.") and ("conv_state" in k or "resblocks" in k) and "conv" in k else 3e-2
         err = (plain[k] - fused[k]).abs().max().item()
         assert err <= tol * scale, (k, err, scale)
+        if k.startswith("dynamics.") and ".bn" in k:      # the same float32 additions in the same order
+            assert torch.equal(plain[k], fused[k]), k
+    assert sum(k.startswith("dynamics.") and ".bn" in k for k in plain) == 10
 
 
 def test_batchnorm_statistics_from_the_convolution():
