@@ -1103,8 +1103,11 @@ class Learner:
             for m in self.network.dynamics.modules():
                 if isinstance(m, nn.BatchNorm2d):
                     m.grad_sum = _BNGradSum()
+        # bf16 learner on a GPU: torch's single-kernel SGD (weight decay, momentum and step in one pass over the
+        # parameters instead of three); the float32 learner keeps the default, the reference's own (train.py:156-159)
+        opt_kw = {"fused": True} if (precision == "bf16" and self.device.type == "cuda") else {}
         self.optimizer = torch.optim.SGD(self.network.parameters(), lr=config.lr_init, momentum=config.momentum,
-                                         weight_decay=config.weight_decay)
+                                         weight_decay=config.weight_decay, **opt_kw)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=config.lr_decay_steps,
                                                          gamma=config.lr_decay_rate)
         self.training_step = 0
