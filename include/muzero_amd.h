@@ -513,6 +513,25 @@ int mz_conv_wgrad_bf16_multi(const void* const* grad_out, const void* const* x, 
                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, float* dw, float* dbias, void* workspace,
                              int64_t workspace_bytes, mz_stream_t stream);
 
+/* The same for SEVERAL 12x12 256->256 layers in one launch (and one reduction): the backward pass of an update
+ * (train.py:303-308) produces the operands of the network's 23 such layers one after the other; computed together
+ * after the pass, a workgroup gets tens of images of ONE layer instead of a handful, and the partial sums that
+ * pass through memory shrink accordingly.  Per layer: host arrays of n_segments (<= 8) device pointers to grad_out
+ * and x (B images each, summed as in mz_conv_wgrad_bf16_multi), dw float [256][256][3][3], dbias optional.  At
+ * most 32 layers and 64 (layer, segment) pairs.  workspace: mz_conv_wgrad_group_workspace_bytes(images per layer =
+ * n_segments * B, n_layers) bytes, 16-byte aligned. */
+typedef struct mz_wgrad_layer {
+  const void* const* grad_out;
+  const void* const* x;
+  int32_t n_segments;
+  int32_t B;
+  float* dw;
+  float* dbias;
+} mz_wgrad_layer;
+int64_t mz_conv_wgrad_group_workspace_bytes(const int32_t* images_per_layer, int32_t n_layers);
+int mz_conv_wgrad_bf16_group(const mz_wgrad_layer* layers, int32_t n_layers, void* workspace, int64_t workspace_bytes,
+                             mz_stream_t stream);
+
 /* Training-mode BatchNorm fused with its surroundings in the reference's blocks (ResidualBlock / DownsampleBlock /
  * DynamicsNetwork, model.py:143-175, :237, as compute_losses runs them, train.py:343, :411):
  *   y = act( batch_norm(x; batch statistics) [+ residual] ),  act = ReLU when relu != 0

@@ -34,6 +34,11 @@ class ChainLayerX3(C.Structure):
                 ("add_residual", C.c_int32)]
 
 
+class WgradLayer(C.Structure):
+    _fields_ = [("grad_out", C.POINTER(C.c_void_p)), ("x", C.POINTER(C.c_void_p)), ("n_segments", C.c_int32),
+                ("B", C.c_int32), ("dw", C.c_void_p), ("dbias", C.c_void_p)]
+
+
 _SIGNATURES = {
     "mz_version": (C.c_int, []),
     "mz_last_error": (C.c_char_p, []),
@@ -91,6 +96,8 @@ _SIGNATURES = {
     "mz_comm_destroy": (C.c_int, [_P]),
     "mz_conv_wgrad_workspace_bytes": (C.c_int64, [C.c_int32]),
     "mz_conv_wgrad_workspace_bytes_for": (C.c_int64, [C.c_int32] * 5),
+    "mz_conv_wgrad_group_workspace_bytes": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
+    "mz_conv_wgrad_bf16_group": (C.c_int, [C.POINTER(WgradLayer), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "mz_step_input_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int32] * 3 + [C.c_void_p]),
     "mz_step_input_grad_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int32] * 4 + [C.c_void_p] * 4),
     "mz_packed_dgrad_s2_elems": (C.c_int64, [C.c_int32, C.c_int32]),

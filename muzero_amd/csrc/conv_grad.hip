@@ -56,21 +56,42 @@ __device__ __forceinline__ f32x4 column_sums(s16x8 a0, s16x8 a1, s16x8 a2, s16x8
 // The images may come in several equally sized segments (the same layer applied at several unroll steps:
 // one pass then produces the sum of their weight gradients): image n is image n % seg_images of segment
 // n / seg_images.
+//
+// One launch may serve several LAYERS (a group): each layer has its own segments, its own number of shares and
+// its own run of workgroups (8 tiles x shares, layer after layer) and of partial-sum slots.  The backward pass of an
+// update produces the operands of 23 such layers one after the other; computed layer by layer, every launch
+// spreads one batch over the whole chip and writes 75 MB of partial sums for 4 images' worth of matrix work per
+// workgroup - computed together after the pass, a workgroup gets 64 images and the partial sums shrink with it.
 constexpr int kMaxSegments = 8;
-struct WgradSrc {
-  const __bf16* gout[kMaxSegments];
-  const __bf16* x[kMaxSegments];
-  int seg_images;
+constexpr int kMaxGroupLayers = 32, kMaxGroupUnits = 64;   // units: (layer, segment) pairs
+struct WgradGroup {
+  const __bf16* gout[kMaxGroupUnits];
+  const __bf16* x[kMaxGroupUnits];
+  int first_unit[kMaxGroupLayers];       // the layer's first (layer, segment) pair
+  int n_images[kMaxGroupLayers];         // all its segments together
+  int seg_images[kMaxGroupLayers];
+  int want_db[kMaxGroupLayers];
+  int first_block[kMaxGroupLayers + 1];  // 8 x (shares of the layers before it)
+  int n_layers;
 };
 
-__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_images, float* __restrict__ partial,
-                                                           float* __restrict__ db_partial) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradGroup grp, float* __restrict__ partial_base,
+                                                           float* __restrict__ db_partial_base) {
+  // which layer this workgroup works for (uniform: scalar registers)
+  int layer = 0;
+  while (layer + 1 < grp.n_layers && (int)blockIdx.x >= grp.first_block[layer + 1]) ++layer;
+  const int local_block = (int)blockIdx.x - grp.first_block[layer];
+  const int shares = (grp.first_block[layer + 1] - grp.first_block[layer]) >> 3;
+  const int n_images = grp.n_images[layer], seg_images = grp.seg_images[layer], unit0 = grp.first_unit[layer];
+  const int slot = (grp.first_block[layer] >> 3) + (local_block >> 3);   // this workgroup's partial-sum slot
+  float* __restrict__ partial = partial_base;
+  float* __restrict__ db_partial = grp.want_db[layer] ? db_partial_base : nullptr;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* gs = lds;
   char* xs = lds + kGBytes;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x & 7, share = blockIdx.x >> 3, shares = gridDim.x >> 3;
+  const int tile = local_block & 7, share = local_block >> 3;
   const int co0 = (tile >> 1) * kCoT, ci0 = (tile & 1) * kCiT;
   const int kq = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
 
@@ -97,9 +118,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
   uint4 g0, g1, g2, x0, x1, x2, x3, x4;
 #define MZ_LOAD_IMAGE(n_)                                                      \
   {                                                                            \
-    const int seg_ = (n_) / src.seg_images, in_seg_ = (n_) - seg_ * src.seg_images;  \
-    const __bf16* gi = src.gout[seg_] + (long)in_seg_ * (kPix * kCh) + co0;    \
-    const __bf16* xi = src.x[seg_] + (long)in_seg_ * (kPix * kCh) + ci0;       \
+    const int seg_ = (n_) / seg_images, in_seg_ = (n_) - seg_ * seg_images;    \
+    const __bf16* gi = grp.gout[unit0 + seg_] + (long)in_seg_ * (kPix * kCh) + co0;  \
+    const __bf16* xi = grp.x[unit0 + seg_] + (long)in_seg_ * (kPix * kCh) + ci0;     \
     g0 = *reinterpret_cast<const uint4*>(gi + gs0);                            \
     g1 = *reinterpret_cast<const uint4*>(gi + gs1);                            \
     g2 = *reinterpret_cast<const uint4*>(gi + gs2);                            \
@@ -172,13 +193,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
 
   if (want_db && (lane & 15) == 0) {  // every column of the product holds the sums; rows 4 kq .. 4 kq + 3
 #pragma unroll
-    for (int r = 0; r < 4; ++r) db_partial[share * kCh + co0 + wave * 16 + 4 * kq + r] = dbv[r];
+    for (int r = 0; r < 4; ++r) db_partial[slot * kCh + co0 + wave * 16 + 4 * kq + r] = dbv[r];
   }
   // partial[share][co][ci][tap] (the layout of dW itself).  A lane holds rows (co) 4 kq .. 4 kq + 3 of column
   // (ci) lane % 16: for one accumulator row r the wavefront owns, in each of 4 rows of dW, 16 ci x 9 taps = 576
   // consecutive bytes.  They pass through a wavefront-private piece of LDS (the staging area is free by now)
   // so that they leave as whole 16-byte units of consecutive addresses.
-  float* dst = partial + (long)share * 9 * kCh * kCh;
+  float* dst = partial + (long)slot * 9 * kCh * kCh;
   float* tr = reinterpret_cast<float*>(lds) + wave * 576;
   const int l16 = lane & 15;
 #pragma unroll
@@ -204,13 +225,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradSrc src, int n_
 // 16th share each (up to eight loads in flight per thread: with 128 shares the whole read is one round trip),
 // then wavefront 0 adds the 16 sums in a fixed order.  dw4: float4s of dW (the grid covers them in 64s), cout:
 // output channels (at most 256).
+// blockIdx.y = layer of a group: layer l owns the partial-sum slots first_slot[l] .. first_slot[l + 1] - 1.
 constexpr int kDw4 = 9 * kCh * kCh / 4;
 constexpr int kRedGroups = 16;
-__global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_kernel(const float4* __restrict__ partial, int shares,
-                                                                      float4* __restrict__ dw,
-                                                                      const float* __restrict__ db_partial,
-                                                                      float* __restrict__ db, int dw4, int cout) {
+struct ReduceGroup {
+  float4* dw[kMaxGroupLayers];
+  float* db[kMaxGroupLayers];
+  int first_slot[kMaxGroupLayers + 1];
+};
+__global__ __launch_bounds__(64 * kRedGroups) void wgrad_reduce_kernel(ReduceGroup rg,
+                                                                      const float4* __restrict__ partial_base,
+                                                                      const float* __restrict__ db_partial_base,
+                                                                      int dw4, int cout) {
   __shared__ float4 part[kRedGroups - 1][64];
+  const int layer = blockIdx.y;
+  const int slot0 = rg.first_slot[layer], shares = rg.first_slot[layer + 1] - slot0;
+  const float4* __restrict__ partial = partial_base + (long)slot0 * dw4;
+  const float* __restrict__ db_partial = db_partial_base + (long)slot0 * cout;
+  float4* __restrict__ dw = rg.dw[layer];
+  float* __restrict__ db = rg.db[layer];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   if (db && blockIdx.x == 0) {  // the bias gradient: four threads per channel, every fourth share each
     __shared__ float dbs[4][256];
@@ -492,8 +525,12 @@ int wg_launch(const void* gout, const void* x, int B, float* dw, float* dbias, v
   float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * C::COUT * C::CIN : nullptr;
   hipLaunchKernelGGL(kern, dim3((shares + 7) / 8 * 8 * C::TILES), dim3(512), C::LDS, s, static_cast<const __bf16*>(gout),
                      static_cast<const __bf16*>(x), B, shares, static_cast<float*>(workspace), dbp);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C::DW4 + 63) / 64), dim3(64 * kRedGroups), 0, s, static_cast<const float4*>(workspace),
-                     shares, reinterpret_cast<float4*>(dw), dbp, dbias, C::DW4, C::COUT);
+  ReduceGroup rg{};
+  rg.dw[0] = reinterpret_cast<float4*>(dw);
+  rg.db[0] = dbias;
+  rg.first_slot[1] = shares;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((C::DW4 + 63) / 64), dim3(64 * kRedGroups), 0, s, rg,
+                     static_cast<const float4*>(workspace), dbp, C::DW4, C::COUT);
   return mz::check_launch("mz_conv_wgrad_bf16");
 }
 
@@ -512,22 +549,85 @@ int64_t mz_conv_wgrad_workspace_bytes(int32_t B) {
   return (int64_t)mz_conv_wgrad_shares(B) * (9 * kCh * kCh + kCh) * 4;  // dW partials, then bias partials
 }
 
-static int wgrad_launch(const WgradSrc& src, int n_images, float* dw, float* dbias, void* workspace,
-                        int64_t workspace_bytes, hipStream_t s, const char* who) {
-  MZ_REQUIRE(((uintptr_t)dw | (uintptr_t)workspace) % 16 == 0, "%s: dw and workspace must be 16-byte aligned", who);
-  MZ_REQUIRE(workspace_bytes >= mz_conv_wgrad_workspace_bytes(n_images), "%s: workspace of %lld bytes, %lld needed", who,
-             (long long)workspace_bytes, (long long)mz_conv_wgrad_workspace_bytes(n_images));
+// one launch of the 12x12 kernel + one of the reduction for a group of layers; shares[l] workgroups x 8 tiles each
+struct HostWgradLayer {
+  const void* const* gout;
+  const void* const* x;
+  int n_segments, B;
+  float* dw;
+  float* db;
+};
+
+static int wgrad_group_launch(const HostWgradLayer* layers, int n_layers, const int* shares, void* workspace,
+                              int64_t workspace_bytes, hipStream_t s, const char* who) {
+  WgradGroup grp{};
+  ReduceGroup rg{};
+  int units = 0, slots = 0;
+  bool any_db = false;
+  for (int l = 0; l < n_layers; ++l) {
+    const HostWgradLayer& L = layers[l];
+    MZ_REQUIRE(L.gout && L.x && L.dw && L.B > 0, "%s: layer %d has a null tensor or an empty batch", who, l);
+    MZ_REQUIRE(L.n_segments >= 1 && L.n_segments <= kMaxSegments, "%s: n_segments = %d outside 1..%d", who, L.n_segments,
+               kMaxSegments);
+    MZ_REQUIRE(units + L.n_segments <= kMaxGroupUnits, "%s: more than %d (layer, segment) pairs", who, kMaxGroupUnits);
+    MZ_REQUIRE((uintptr_t)L.dw % 16 == 0, "%s: dw must be 16-byte aligned", who);
+    grp.first_unit[l] = units;
+    for (int i = 0; i < L.n_segments; ++i) {
+      MZ_REQUIRE(L.gout[i] && L.x[i], "%s: segment %d has a null tensor", who, i);
+      grp.gout[units] = static_cast<const __bf16*>(L.gout[i]);
+      grp.x[units] = static_cast<const __bf16*>(L.x[i]);
+      ++units;
+    }
+    grp.n_images[l] = L.n_segments * L.B;
+    grp.seg_images[l] = L.B;
+    grp.want_db[l] = L.db != nullptr;
+    any_db |= L.db != nullptr;
+    grp.first_block[l] = 8 * slots;
+    rg.dw[l] = reinterpret_cast<float4*>(L.dw);
+    rg.db[l] = L.db;
+    rg.first_slot[l] = slots;
+    slots += shares[l];
+  }
+  grp.first_block[n_layers] = 8 * slots;
+  grp.n_layers = n_layers;
+  rg.first_slot[n_layers] = slots;
+  const int64_t need = (int64_t)slots * (9 * kCh * kCh + kCh) * 4;
+  MZ_REQUIRE((uintptr_t)workspace % 16 == 0, "%s: workspace must be 16-byte aligned", who);
+  MZ_REQUIRE(workspace_bytes >= need, "%s: workspace of %lld bytes, %lld needed", who, (long long)workspace_bytes,
+             (long long)need);
   static bool configured[mz::kMaxDevices] = {false};
   if (int rc = mz::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_wgrad_kernel), kWgradLds, configured,
                                       "conv_wgrad"))
     return rc;
-  const int shares = mz_conv_wgrad_shares(n_images);
-  float* dbp = dbias ? static_cast<float*>(workspace) + (long)shares * 9 * kCh * kCh : nullptr;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * shares), dim3(512), kWgradLds, s, src, n_images,
-                     static_cast<float*>(workspace), dbp);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kDw4 + 63) / 64), dim3(64 * kRedGroups), 0, s, static_cast<const float4*>(workspace),
-                     shares, reinterpret_cast<float4*>(dw), dbp, dbias, kDw4, kCh);
+  float* partial = static_cast<float*>(workspace);
+  float* dbp = partial + (long)slots * 9 * kCh * kCh;   // (written only by layers that want a bias gradient)
+  (void)any_db;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(8 * slots), dim3(512), kWgradLds, s, grp, partial, dbp);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kDw4 + 63) / 64, n_layers), dim3(64 * kRedGroups), 0, s, rg,
+                     reinterpret_cast<const float4*>(partial), dbp, kDw4, kCh);
   return mz::check_launch(who);
+}
+
+// shares per layer of a group: 64 images per workgroup - unless that leaves compute units without work (then as
+// many workgroups as there are units) or needs more than kMaxGroupSlots partial-sum slots (then more images each)
+constexpr int kMaxGroupSlots = 128;
+static void group_shares(const int* images, int n_layers, int* shares) {
+  long total = 0;
+  for (int l = 0; l < n_layers; ++l) total += images[l];
+  const int cus = mz::compute_units();
+  long quota = 64;
+  if (total * 8 / quota < cus) quota = (total * 8 + cus - 1) / cus;
+  if (quota < 1) quota = 1;
+  for (;;) {
+    long slots = 0;
+    for (int l = 0; l < n_layers; ++l) slots += (images[l] + quota - 1) / quota;
+    if (slots <= kMaxGroupSlots) break;
+    quota += quota / 4 + 1;
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    const long sh = (images[l] + quota - 1) / quota;
+    shares[l] = (int)(sh < 1 ? 1 : sh);
+  }
 }
 
 int64_t mz_conv_wgrad_workspace_bytes_for(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
@@ -554,11 +654,9 @@ int mz_conv_wgrad_bf16(const void* grad_out, const void* x, int32_t B, int32_t H
     return mz::fail(MZ_E_ARG, "mz_conv_wgrad_bf16: no kernel for a %dx%d input, %d->%d channels (the reference "
                     "architecture's five layer shapes have one)", H, W, Cin, Cout);
   }
-  WgradSrc src{};
-  src.gout[0] = static_cast<const __bf16*>(grad_out);
-  src.x[0] = static_cast<const __bf16*>(x);
-  src.seg_images = B;
-  return wgrad_launch(src, B, dw, dbias, workspace, workspace_bytes, mz::as_stream(stream), "mz_conv_wgrad_bf16");
+  const HostWgradLayer layer{&grad_out, &x, 1, B, dw, dbias};
+  const int shares = mz_conv_wgrad_shares(B);
+  return wgrad_group_launch(&layer, 1, &shares, workspace, workspace_bytes, mz::as_stream(stream), "mz_conv_wgrad_bf16");
 }
 
 int mz_conv_wgrad_bf16_multi(const void* const* grad_out, const void* const* x, int32_t n_segments, int32_t B,
@@ -570,15 +668,37 @@ int mz_conv_wgrad_bf16_multi(const void* const* grad_out, const void* const* x, 
   MZ_REQUIRE(H == kSide && W == kSide && Cin == kCh && Cout == kCh,
              "mz_conv_wgrad_bf16_multi: only the 12x12, 256->256 layer shape has a kernel (got %dx%d, %d->%d)", H, W, Cin,
              Cout);
-  WgradSrc src{};
-  for (int i = 0; i < n_segments; ++i) {
-    MZ_REQUIRE(grad_out[i] && x[i], "mz_conv_wgrad_bf16_multi: segment %d has a null tensor", i);
-    src.gout[i] = static_cast<const __bf16*>(grad_out[i]);
-    src.x[i] = static_cast<const __bf16*>(x[i]);
+  const HostWgradLayer layer{grad_out, x, n_segments, B, dw, dbias};
+  const int shares = mz_conv_wgrad_shares(n_segments * B);
+  return wgrad_group_launch(&layer, 1, &shares, workspace, workspace_bytes, mz::as_stream(stream),
+                            "mz_conv_wgrad_bf16_multi");
+}
+
+int64_t mz_conv_wgrad_group_workspace_bytes(const int32_t* images_per_layer, int32_t n_layers) {
+  if (!images_per_layer || n_layers <= 0 || n_layers > kMaxGroupLayers) return 0;
+  int shares[kMaxGroupLayers];
+  group_shares(images_per_layer, n_layers, shares);
+  int64_t slots = 0;
+  for (int l = 0; l < n_layers; ++l) slots += shares[l];
+  return slots * (9 * kCh * kCh + kCh) * 4;
+}
+
+int mz_conv_wgrad_bf16_group(const mz_wgrad_layer* layers, int32_t n_layers, void* workspace, int64_t workspace_bytes,
+                             mz_stream_t stream) {
+  MZ_REQUIRE(layers && workspace, "mz_conv_wgrad_bf16_group: null argument");
+  MZ_REQUIRE(n_layers >= 1 && n_layers <= kMaxGroupLayers, "mz_conv_wgrad_bf16_group: n_layers = %d outside 1..%d", n_layers,
+             kMaxGroupLayers);
+  HostWgradLayer host[kMaxGroupLayers];
+  int images[kMaxGroupLayers], shares[kMaxGroupLayers];
+  for (int l = 0; l < n_layers; ++l) {
+    host[l] = HostWgradLayer{layers[l].grad_out, layers[l].x, layers[l].n_segments, layers[l].B, layers[l].dw,
+                             layers[l].dbias};
+    MZ_REQUIRE(layers[l].n_segments >= 1 && layers[l].B > 0, "mz_conv_wgrad_bf16_group: layer %d is empty", l);
+    images[l] = layers[l].n_segments * layers[l].B;
   }
-  src.seg_images = B;
-  return wgrad_launch(src, n_segments * B, dw, dbias, workspace, workspace_bytes, mz::as_stream(stream),
-                      "mz_conv_wgrad_bf16_multi");
+  group_shares(images, n_layers, shares);
+  return wgrad_group_launch(host, n_layers, shares, workspace, workspace_bytes, mz::as_stream(stream),
+                            "mz_conv_wgrad_bf16_group");
 }
 
 }  // extern "C"

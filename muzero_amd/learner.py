@@ -240,6 +240,48 @@ class Conv3x3(nn.Conv2d):
                 if p.requires_grad:
                     p.grad = g if p.grad is None else p.grad + g
 
+    @staticmethod
+    def flush_wgrad_group(convs) -> None:
+        """The deferred weight (and bias) gradients of SEVERAL 12x12 256->256 layers from one kernel pass and one
+        reduction (mz_conv_wgrad_bf16_group): each layer's recorded (grad_out, x) pairs are its segments.  Layers
+        the group form cannot take (more than 8 segments, unequal batches) go through ``flush_wgrad``."""
+        todo = []
+        for m in convs:
+            pend = m._packed.pending
+            if not pend:
+                continue
+            same = all(g.shape[0] == pend[0][0].shape[0] for g, _ in pend)
+            if (m.in_channels, m.out_channels, m.stride[0]) == (256, 256, 1) and len(pend) <= 8 and same:
+                todo.append((m, pend))
+                m._packed.pending = []
+            else:
+                m.flush_wgrad()
+        while todo:                       # at most 32 layers and 64 (layer, segment) pairs per launch
+            batch, pairs = [], 0
+            while todo and len(batch) < 32 and pairs + len(todo[0][1]) <= 64:
+                pairs += len(todo[0][1])
+                batch.append(todo.pop(0))
+            dev = batch[0][0].weight.device
+            n = len(batch)
+            arr = (_lib.WgradLayer * n)()
+            keep, outs = [], []
+            images = (C.c_int32 * n)()
+            for i, (m, pend) in enumerate(batch):
+                gp = (C.c_void_p * len(pend))(*[g.data_ptr() for g, _ in pend])
+                xp = (C.c_void_p * len(pend))(*[x.data_ptr() for _, x in pend])
+                dw = torch.empty(256, 256, 3, 3, dtype=torch.float32, device=dev)
+                db = torch.empty(256, dtype=torch.float32, device=dev)
+                keep += [gp, xp]
+                outs.append((m, dw, db))
+                arr[i] = _lib.WgradLayer(gp, xp, len(pend), pend[0][0].shape[0], dw.data_ptr(), db.data_ptr())
+                images[i] = len(pend) * pend[0][0].shape[0]
+            ws = _wgrad_workspace(_lib.lib().mz_conv_wgrad_group_workspace_bytes(images, n), dev)
+            _lib.call("mz_conv_wgrad_bf16_group", arr, n, _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+            for m, dw, db in outs:
+                for p, g in ((m.weight, dw), (m.bias, db)):
+                    if p.requires_grad:
+                        p.grad = g if p.grad is None else p.grad + g
+
     def runs_native(self, x) -> bool:
         side = _NATIVE_LAYERS.get((self.in_channels, self.out_channels, self.stride[0]))
         return (self.native and x.is_cuda and torch.is_autocast_enabled() and side is not None
@@ -1314,21 +1356,23 @@ class Learner:
                 m._packed.mark_current(m.weight, t)
 
     def _backward(self, loss) -> None:
-        """loss.backward() with the gradients of the dynamics network's layers - applied once per unroll step -
-        summed by this library instead of by autograd: the native convolutions' weight gradients come from one
-        kernel pass per layer over all steps, the fused BatchNorms add each step's affine gradients into a running
-        sum."""
+        """loss.backward() with the weight gradients of all 12x12 256->256 convolutions computed after the pass by one
+        kernel launch (the dynamics network's layers, applied once per unroll step, summed over their steps in it),
+        and the dynamics BatchNorms adding each step's affine gradients into a running sum in their kernel - instead
+        of a launch per layer and step and autograd's additions."""
         mods = list(self.network.dynamics.modules()) if self.native_convs else []
-        convs = [m for m in mods if isinstance(m, Conv3x3)]
         norms = [m for m in mods if isinstance(m, nn.BatchNorm2d) and getattr(m, "grad_sum", None) is not None]
+        # every 12x12 256->256 convolution of the network - the dynamics network's (applied once per unroll step) and
+        # the representation network's - records its operands during the pass; one launch computes all of them after it
+        convs = [m for m in self.network.modules() if isinstance(m, Conv3x3)
+                 and (m.in_channels, m.out_channels, m.stride[0]) == (256, 256, 1)] if self.native_convs else []
         for m in convs:
             m.defer_wgrad(True)
         for m in norms:
             m.grad_sum.active = True
         try:
             loss.backward()
-            for m in convs:
-                m.flush_wgrad()
+            Conv3x3.flush_wgrad_group(convs)
             for m in norms:
                 for p, g in zip((m.weight, m.bias), m.grad_sum.take()):
                     if g is not None and p.requires_grad:

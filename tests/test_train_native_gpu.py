@@ -418,6 +418,56 @@ def test_wgrad_over_several_segments_equals_the_sum_of_single_calls():
                   ws.numel() * 4, _lib.current_stream())
 
 
+def test_wgrad_of_a_group_of_layers_equals_the_single_layer_calls():
+    """mz_conv_wgrad_bf16_group on four layers of different batch sizes and segment counts (one launch, one
+    reduction) against mz_conv_wgrad_bf16_multi layer by layer: the same products in another split into shares, so
+    float32 summation order only; a layer without a bias gradient leaves it alone; twice for identical bits."""
+    import ctypes as C
+    from muzero_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    spec = [(1, 128, True), (5, 37, True), (2, 64, False), (8, 3, True)]            # segments, images each, bias gradient
+    data = [[(_bf16(torch.randn(B, 12, 12, 256, generator=g) * 0.1).cuda(), _bf16(torch.randn(B, 12, 12, 256, generator=g)).cuda())
+             for _ in range(S)] for S, B, _ in spec]
+    n = len(spec)
+
+    def run_group():
+        arr = (_lib.WgradLayer * n)()
+        keep, outs = [], []
+        images = (C.c_int32 * n)(*[S * B for S, B, _ in spec])
+        for i, ((S, B, with_db), segs) in enumerate(zip(spec, data)):
+            gp = (C.c_void_p * S)(*[a.data_ptr() for a, _ in segs])
+            xp = (C.c_void_p * S)(*[b.data_ptr() for _, b in segs])
+            dw = torch.full((256, 256, 3, 3), float("nan"), device="cuda")
+            db = torch.full((256,), 7.0, device="cuda")
+            keep += [gp, xp]
+            outs.append((dw, db))
+            arr[i] = _lib.WgradLayer(gp, xp, S, B, dw.data_ptr(), db.data_ptr() if with_db else None)
+        need = _lib.lib().mz_conv_wgrad_group_workspace_bytes(images, n)
+        ws = torch.full((need // 4,), float("nan"), device="cuda")
+        _lib.call("mz_conv_wgrad_bf16_group", arr, n, _lib.ptr(ws), need, _lib.current_stream())
+        with pytest.raises(_lib.MuZeroAmdError, match="workspace"):
+            _lib.call("mz_conv_wgrad_bf16_group", arr, n, _lib.ptr(ws), need - 4, _lib.current_stream())
+        torch.cuda.synchronize()
+        return outs
+
+    first, second = run_group(), run_group()
+    for (S, B, with_db), segs, (dw, db), (dw2, db2) in zip(spec, data, first, second):
+        gp = (C.c_void_p * S)(*[a.data_ptr() for a, _ in segs])
+        xp = (C.c_void_p * S)(*[b.data_ptr() for _, b in segs])
+        need = _lib.lib().mz_conv_wgrad_workspace_bytes(S * B)
+        ws = torch.empty(need // 4, device="cuda")
+        dw_ref = torch.empty(256, 256, 3, 3, device="cuda")
+        db_ref = torch.empty(256, device="cuda")
+        _lib.call("mz_conv_wgrad_bf16_multi", gp, xp, S, B, 12, 12, 256, 256, _lib.ptr(dw_ref), _lib.ptr(db_ref),
+                  _lib.ptr(ws), need, _lib.current_stream())
+        assert (dw - dw_ref).abs().max().item() <= 2e-5 * dw_ref.abs().max().item()
+        if with_db:
+            assert (db - db_ref).abs().max().item() <= 2e-5 * db_ref.abs().max().item() + 1e-5
+        else:
+            assert bool((db == 7.0).all())
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 def test_deferred_weight_gradients_equal_the_per_step_ones():
     """Learner._backward (the dynamics convolutions' weight gradients from one kernel pass over all unroll steps,
     the dynamics BatchNorms' affine gradients summed inside their backward kernel) against a plain
@@ -448,9 +498,14 @@ def test_deferred_weight_gradients_equal_the_per_step_ones():
         # the dynamics convolutions differ by the order of the float32 partial sums only; layers further back inherit
         # that difference through bf16 activations' gradients, and MIOpen's split-K weight gradients (atomics) do
         # not repeat bit for bit between two runs anyway
-        tol = 1e-4 if k.startswith("dynamics.") and ("conv_state" in k or "resblocks" in k) and "conv" in k else 3e-2
+        trunk_conv = "conv" in k and (k.startswith("dynamics.") and ("conv_state" in k or "resblocks" in k)
+                                      or k.startswith("representation.resblocks")
+                                      or k.startswith("representation.downsample.1.blocks"))
+        tol = 1e-4 if trunk_conv else 3e-2
         err = (plain[k] - fused[k]).abs().max().item()
-        assert err <= tol * scale, (k, err, scale)
+        # (a convolution bias in front of a training-mode BatchNorm has a zero gradient in exact arithmetic: what both
+        # sides hold there is float32 summation noise of ~1e-5, hence the absolute floor)
+        assert err <= tol * scale + 1e-7, (k, err, scale)
         if k.startswith("dynamics.") and ".bn" in k:      # the same float32 additions in the same order
             assert torch.equal(plain[k], fused[k]), k
     assert sum(k.startswith("dynamics.") and ".bn" in k for k in plain) == 10
