@@ -23,7 +23,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/f
 python3 tools/top_kernels.py $out/f16 14 > $out/${tag}_f16_kernels.txt
 echo "f16 pass done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out/train -- python3 tools/profile_train.py 128 bf16 native graphed > /dev/null 2> $out/train.err
-python3 tools/last_window.py $out/train 10.7 40 > $out/${tag}_train_update.txt
+python3 tools/last_window.py $out/train 7.9 60 > $out/${tag}_train_update.txt
 echo "train pass done"
 # keep only what the summaries need (the traces are tens of MB)
 find $out -name "*kernel_trace.csv" -delete
