@@ -511,6 +511,44 @@ def test_deferred_weight_gradients_equal_the_per_step_ones():
     assert sum(k.startswith("dynamics.") and ".bn" in k for k in plain) == 10
 
 
+@pytest.mark.parametrize("K", [0, 1, 9])
+def test_deferred_gradients_at_other_unroll_lengths(K):
+    """No unroll step (the dynamics network unused: its parameters get no gradient), one, and nine - more segments
+    than one grouped launch takes per layer, so those layers fall back to launches of eight and one: Learner._backward
+    against a plain loss.backward() on the dynamics convolutions' and BatchNorms' gradients."""
+    from muzero_amd.config import MuZeroConfig
+    from muzero_amd.learner import Learner
+    from muzero_amd.network import init_state_dict
+    cfg = MuZeroConfig()
+    cfg.observation_shape, cfg.action_space_size, cfg.num_unroll_steps = (96, 96, 96), 6, K
+    sd = init_state_dict(cfg, seed=2)
+    rng = np.random.default_rng(2)
+    B, A = 4, 6
+    batch = (torch.from_numpy(rng.random((B, 96, 96, 96), dtype=np.float32)), rng.integers(0, A, (B, K)),
+             rng.normal(0, 3, (B, K + 1)), rng.normal(0, 1, (B, K + 1)), rng.dirichlet(np.ones(A), (B, K + 1)), np.ones(B))
+    grads = []
+    for deferred in (False, True):
+        lrn = Learner(cfg, state_dict=sd, precision="bf16", native_convs=True)
+        loss = lrn.losses_from_tensors(*batch)[3].mean()
+        if deferred:
+            lrn._backward(loss)
+        else:
+            loss.backward()
+        grads.append({k: (None if p.grad is None else p.grad.detach().float().clone())
+                      for k, p in lrn.network.named_parameters()})
+    plain, fused = grads
+    for k in plain:
+        assert (plain[k] is None) == (fused[k] is None), k
+        if plain[k] is None:
+            assert K == 0 and (k.startswith("dynamics.")), k
+            continue
+        if k.startswith("dynamics.") and ".bn" in k:
+            assert torch.equal(plain[k], fused[k]), k
+        elif k.startswith("dynamics.") and "conv" in k and "conv_action" not in k:
+            scale = plain[k].abs().max().item()
+            assert (plain[k] - fused[k]).abs().max().item() <= 1e-4 * scale + 1e-7, k
+
+
 def test_batchnorm_statistics_from_the_convolution():
     """conv_bn_act (the convolution writes per-image column sums of its rounded outputs, the BatchNorm takes its
     batch statistics from them) against the convolution followed by the BatchNorm's own statistics pass: same
