@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="let MIOpen search its convolution solvers")
     ap.add_argument("--rows", type=int, default=1024 * 6, help="loss rows: batch 1024 x (K+1) unroll steps")
+    ap.add_argument("--only", default="", help="comma-separated variants to run (default: all five)")
     args = ap.parse_args()
     dev = torch.device("cuda")
     torch.backends.cudnn.benchmark = args.autotune
@@ -108,6 +109,8 @@ def main():
                                             ("bf16_native_convs", "bf16", True, False),
                                             ("bf16_torch_convs_graphed", "bf16", False, True),
                                             ("bf16_native_convs_graphed", "bf16", True, True)):
+        if args.only and tag not in args.only.split(","):
+            continue
         lrn = Learner(cfg, device=dev, state_dict=init_state_dict(cfg, seed=0), precision=precision,
                       native_convs=native, autotune=args.autotune)
         if graphed:
@@ -125,6 +128,7 @@ def main():
         out["update_weights_" + tag] = {"batch": B, "unroll": K, "ms_per_step": dt * 1e3,
                                               "positions_per_s": B / dt, "model_TFLOP/s": 3 * fwd * B / dt / 1e12,
                                               "loss": m["total_loss"]}
+        print(f"{tag}: {dt * 1e3:.2f} ms per update", file=sys.stderr, flush=True)     # (a long run stays audible)
         del lrn
     print(json.dumps(out))
 
