@@ -660,3 +660,73 @@ def test_step_input_and_its_gradient_against_torch(N, A):
     (hb.mean(dim=(2, 3)) * upm).sum().backward()
     assert (m - hb.mean(dim=(2, 3))).abs().max().item() <= 1e-5 * m.abs().max().item() + 1e-6
     assert (ha.grad.float() - hb.grad).abs().max().item() <= 4e-3 * hb.grad.abs().max().item()
+
+
+def _guarded(shape, dtype, fill=0.0, guard=4096):
+    """A tensor of `shape` in the middle of a larger buffer whose margins hold a canary; returns (tensor, check)."""
+    n = int(np.prod(shape))
+    canary = 1234.5 if dtype.is_floating_point else 77
+    buf = torch.full((n + 2 * guard,), canary, dtype=dtype, device="cuda")
+    t = buf[guard:guard + n].view(shape)
+    t.fill_(fill)
+
+    def check():
+        assert bool((buf[:guard] == canary).all()) and bool((buf[guard + n:] == canary).all()), "write outside the tensor"
+    return t, check
+
+
+@pytest.mark.parametrize("H,cin,cout,s", OTHER_SHAPES + [(12, 256, 256, 1)])
+def test_training_kernels_write_inside_their_outputs(H, cin, cout, s):
+    """Every output and workspace of the backward kernels sits between canaries: the weight gradient (dW, bias
+    gradient, partial-sum workspace at exactly the size the library asks for), the stride-2 data gradient, the
+    one-pass step input and its gradient - at a batch whose shares and bands do not divide evenly."""
+    from muzero_amd import _lib
+    from muzero_amd.learner import pack_dgrad_s2
+    N, Ho = 5, H // s
+    g = torch.Generator().manual_seed(H + cin)
+    x = _bf16(torch.randn(N, H, H, cin, generator=g)).cuda()
+    go = _bf16(torch.randn(N, Ho, Ho, cout, generator=g) * 0.1).cuda()
+    need = _lib.lib().mz_conv_wgrad_workspace_bytes_for(N, H, H, cin, cout)
+    checks = []
+    ws, c = _guarded((need // 4,), torch.float32); checks.append(c)
+    dw, c = _guarded((cout, cin, 3, 3), torch.float32); checks.append(c)
+    db, c = _guarded((cout,), torch.float32); checks.append(c)
+    _lib.call("mz_conv_wgrad_bf16", _lib.ptr(go), _lib.ptr(x), N, H, H, cin, cout, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws),
+              need, _lib.current_stream())
+    if s == 2 and cin != 96:
+        w = torch.randn(cout, cin, 3, 3, generator=g).cuda()
+        dx, c = _guarded((N, H, H, cin), torch.bfloat16); checks.append(c)
+        _lib.call("mz_conv_dgrad_s2_bf16", _lib.ptr(go), _lib.ptr(pack_dgrad_s2(w)), _lib.ptr(dx), N, H, H, cin, cout,
+                  _lib.current_stream())
+    if (H, cin) == (12, 256):
+        A = 18
+        table = torch.randn(A, cin, generator=g).cuda()
+        actions = torch.randint(0, A, (N,), generator=g).cuda().to(torch.int32)
+        xo, c = _guarded((N, H, H, cin), torch.bfloat16); checks.append(c)
+        mean, c = _guarded((N, cin), torch.float32); checks.append(c)
+        _lib.call("mz_step_input_bf16", _lib.ptr(x), _lib.ptr(table), _lib.ptr(actions), _lib.ptr(xo), _lib.ptr(mean), N,
+                  H * H, cin, _lib.current_stream())
+        dh, c = _guarded((N, H, H, cin), torch.bfloat16); checks.append(c)
+        sums, c = _guarded((N, cin), torch.float32); checks.append(c)
+        dt, c = _guarded((A, cin), torch.float32); checks.append(c)
+        _lib.call("mz_step_input_grad_bf16", _lib.ptr(go), _lib.ptr(mean), _lib.ptr(actions), N, H * H, cin, A, _lib.ptr(dh),
+                  _lib.ptr(sums), _lib.ptr(dt), _lib.current_stream())
+        # a group of two layers with two segments each
+        import ctypes as C
+        segs = [(go, x), (x, go)]
+        arr = (_lib.WgradLayer * 2)()
+        keep = []
+        images = (C.c_int32 * 2)(2 * N, 2 * N)
+        gneed = _lib.lib().mz_conv_wgrad_group_workspace_bytes(images, 2)
+        gws, c = _guarded((gneed // 4,), torch.float32); checks.append(c)
+        for i in range(2):
+            gp = (C.c_void_p * 2)(*[a.data_ptr() for a, _ in segs])
+            xp = (C.c_void_p * 2)(*[b.data_ptr() for _, b in segs])
+            gdw, c = _guarded((256, 256, 3, 3), torch.float32); checks.append(c)
+            gdb, c = _guarded((256,), torch.float32); checks.append(c)
+            keep += [gp, xp, gdw, gdb]
+            arr[i] = _lib.WgradLayer(gp, xp, 2, N, gdw.data_ptr(), gdb.data_ptr())
+        _lib.call("mz_conv_wgrad_bf16_group", arr, 2, _lib.ptr(gws), gneed, _lib.current_stream())
+    torch.cuda.synchronize()
+    for c in checks:
+        c()
