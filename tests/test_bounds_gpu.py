@@ -14,7 +14,7 @@ SHAPES = {"stem": (96, 96, 256, 2), "down0": (48, 256, 128, 2), "mid": (24, 128,
 def guarded(shape, dtype, guard=8192):
     """A tensor of `shape` between two canary margins of one buffer; returns (tensor, check)."""
     n = int(np.prod(shape))
-    canary = 1234.5
+    canary = 1234.5 if dtype.is_floating_point else 77
     buf = torch.full((n + 2 * guard,), canary, dtype=dtype, device="cuda")
     t = buf[guard:guard + n].view(shape)
     t.zero_()
@@ -115,3 +115,50 @@ def test_rotating_observation_and_first_convolution(B):
     torch.cuda.synchronize()
     check_rot(); check_out()
     assert bool(torch.isfinite(out.float()).all()) and float(out.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("B,A", [(1, 4), (37, 18), (130, 64)])
+def test_tree_workspace_and_heads(B, A):
+    """A 50-simulation search on random priors with the trees' workspace between canaries (the staged
+    backup-and-descent launch and the plain kernels), and the heads kernel writing into guarded outputs."""
+    import ctypes as C
+    from muzero_amd import _lib
+    from muzero_amd.tree import DeviceTrees
+    from tests.test_bf16_gpu import _nets
+    g = torch.Generator().manual_seed(B)
+    sims = 50
+    trees = DeviceTrees(B, A, sims + 1)
+    ws, check_ws = guarded((trees.layout.total_bytes,), torch.uint8, guard=1 << 16)
+    trees.ws = ws
+    pri = torch.softmax(torch.randn(B, A, generator=g), dim=1).cuda()
+    noise = torch.distributions.Dirichlet(torch.full((A,), 0.3)).sample((B,)).double().cuda()
+    trees.root_init(pri, noise, 0.25)
+    trees.select()
+    for s in range(sims):
+        p = torch.softmax(torch.randn(B, A, generator=g), dim=1).cuda()
+        v = torch.randn(B, generator=g).cuda()
+        r = torch.randn(B, generator=g).cuda()
+        if s + 1 < sims:
+            trees.expand_backup_select(p, v, r, 1, 0.997)
+        else:
+            trees.expand_backup(p, v, r, 1, 0.997)
+    visits, check_v = guarded((B, A), torch.int32, guard=4096)
+    rootv, check_r = guarded((B,), torch.float64, guard=4096)
+    probs, check_p = guarded((B, A), torch.float64, guard=4096)
+    trees.readout(visits, rootv, probs)
+    torch.cuda.synchronize()
+    for c in (check_ws, check_v, check_r, check_p):
+        c()
+    assert bool((visits.sum(1) == sims).all())
+    if A in (6, 18):                                    # the heads of a full-size network (the fixture's action counts)
+        cfg, ref, net = _nets(A)
+        mean = torch.randn(B, 256, generator=g).cuda()
+        O = 2 * net.S + 1
+        outs = [guarded(shape, torch.float32, guard=4096) for shape in ((B, A), (B,), (B,), (B, A), (B, O), (B, O))]
+        _lib.call("mz_heads", _lib.ptr(mean), B, net.W, net.policy.hidden, net.A, net.S, C.byref(net.policy.c),
+                  C.byref(net.value_head.c), C.byref(net.reward_head.c), *[_lib.ptr(t) for t, _ in outs],
+                  _lib.current_stream())
+        torch.cuda.synchronize()
+        for t, c in outs:
+            c()
+            assert bool(torch.isfinite(t).all())
