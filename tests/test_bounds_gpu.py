@@ -162,3 +162,52 @@ def test_tree_workspace_and_heads(B, A):
         for t, c in outs:
             c()
             assert bool(torch.isfinite(t).all())
+
+
+def test_weight_packing_and_replay_kernels():
+    """The device-side weight packing (forward fragments with their zero k-steps, the stride-2 data-gradient form,
+    the heads' linear layers) and the replay sampler / priority write-back with every output and workspace between
+    canaries, at sizes that are not multiples of the kernels' block shapes."""
+    from muzero_amd import _lib
+    g = torch.Generator().manual_seed(9)
+    checks = []
+    for cout, cin, chunk in ((256, 96, 96), (128, 256, 64), (256, 256, 256)):
+        w = torch.randn(cout, cin, 3, 3, generator=g).cuda()
+        n = _lib.lib().mz_packed_conv_elems(cout, cin, 0)
+        out, c = guarded((n,), torch.bfloat16); checks.append(c)
+        bias_out, c = guarded((cout,), torch.float32); checks.append(c)
+        cb = torch.zeros(cout, device="cuda")
+        _lib.call("mz_weights_fold_pack", _lib.ptr(w), _lib.ptr(cb), None, None, None, None, 1e-5, cout, cin, chunk, 0, 0, 0,
+                  _lib.ptr(out), _lib.ptr(bias_out), _lib.current_stream())
+    for cout, cin in ((128, 256), (256, 128)):
+        w = torch.randn(cout, cin, 3, 3, generator=g).cuda()
+        out, c = guarded((_lib.lib().mz_packed_dgrad_s2_elems(cout, cin),), torch.bfloat16); checks.append(c)
+        _lib.call("mz_weights_pack_dgrad_s2", _lib.ptr(w), cout, cin, _lib.ptr(out), _lib.current_stream())
+    for O, K in ((18, 256), (601, 256)):
+        w = torch.randn(O, K, generator=g).cuda()
+        b = torch.randn(O, generator=g).cuda()
+        tiles = (O + 15) // 16
+        wp, c = guarded((tiles * 16 * K,), torch.float16); checks.append(c)
+        bp, c = guarded((tiles * 16,), torch.float32); checks.append(c)
+        _lib.call("mz_pack_linear", _lib.ptr(w), _lib.ptr(b), O, K, 2, _lib.ptr(wp), _lib.ptr(bp), _lib.current_stream())
+    # replay: 100 003 positions in 37 games, 1000 draws
+    n, games, batch = 100003, 37, 1000
+    prio, c = guarded((n,), torch.float64); checks.append(c)
+    prio.copy_(torch.rand(n, generator=g, dtype=torch.float64).cuda())
+    cuts = np.sort(np.random.default_rng(1).choice(np.arange(1, n), games - 1, replace=False))
+    starts = torch.tensor(np.concatenate([[0], cuts, [n]]), dtype=torch.int64, device="cuda")
+    u = torch.rand(batch, generator=g, dtype=torch.float64).cuda()
+    flat, c = guarded((batch,), torch.int32); checks.append(c)
+    game, c = guarded((batch,), torch.int32); checks.append(c)
+    pos, c = guarded((batch,), torch.int32); checks.append(c)
+    wts, c = guarded((batch,), torch.float64); checks.append(c)
+    need = _lib.lib().mz_replay_workspace_bytes(n)
+    ws, c = guarded(((need + 7) // 8,), torch.float64); checks.append(c)
+    _lib.call("mz_replay_sample", _lib.ptr(prio), n, _lib.ptr(u), batch, 1.0, _lib.ptr(starts), games, _lib.ptr(flat),
+              _lib.ptr(game), _lib.ptr(pos), _lib.ptr(wts), _lib.ptr(ws), need, _lib.current_stream())
+    vals = torch.rand(batch, generator=g, dtype=torch.float64).cuda()
+    _lib.call("mz_replay_update", _lib.ptr(prio), n, _lib.ptr(flat), _lib.ptr(vals), batch, 1.0, _lib.current_stream())
+    torch.cuda.synchronize()
+    for c in checks:
+        c()
+    assert bool(((flat >= 0) & (flat < n)).all())
